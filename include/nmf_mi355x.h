@@ -1,0 +1,213 @@
+/*
+ * nmf_mi355x.h -- C ABI of libnmf_mi355x.so: the MI355X (gfx950) implementation of the
+ * reference's KL-divergence multiplicative-update NMF hot path (update_div, X ~ W*H).
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).  Plain pointers and sizes only; no torch / C++ types.
+ * All matrices are fp32, column-major, leading dimension = rows (README.md:31-36).
+ */
+#ifndef NMF_MI355X_H
+#define NMF_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------
+ * The reference's matrix struct (README.md:31-36: "column-major float array ... proper
+ * assignment of the dim values"; upstream layout {mat, mat_d, dim[2]}).  `mat` is the
+ * host buffer (dim[0] x dim[1], ld = dim[0], unpadded); `mat_d` an optional device buffer
+ * of the same unpadded layout (NULL when absent).  Replaces class Matrix,
+ * cuda/matrix.cuh:18-39.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    float *mat;
+    float *mat_d;
+    int    dim[2];
+} matrix;
+
+/* EPS exactly as cuda/matrix.cu:10 */
+#define NMF_EPS ((float)(2.2204E-16))
+/* cuda/nmf.cu:9 */
+#define NMF_ITER_CHECK_DEFAULT 25
+
+/* status codes (the reference has none: it prints and exit()s, error-check.hpp:12-17) */
+enum {
+    NMF_OK = 0,
+    NMF_ERR_ARG = 1,        /* NULL pointer / non-positive dimension */
+    NMF_ERR_SHAPE = 2,      /* "dimensions do not agree" (cuda/matrix.cu:130-134 etc.) */
+    NMF_ERR_HIP = 3,        /* a HIP runtime call or kernel launch failed */
+    NMF_ERR_IO = 4,         /* fopen / fread / fwrite failure (cuda/nmf.cu:196-205) */
+    NMF_ERR_NOMEM = 5,
+    NMF_ERR_COMM = 6,       /* RCCL failure */
+    NMF_ERR_UNSUPPORTED = 7
+};
+
+/* which device path update_div runs */
+enum {
+    NMF_PATH_AUTO = 0,      /* fused when K (padded to 32) <= 256, else unfused */
+    NMF_PATH_FUSED = 1,     /* two fused MFMA kernels per iteration, Z never reaches HBM */
+    NMF_PATH_UNFUSED = 2    /* op-for-op twin of cuda/nmf.cu:118-176 (16 kernels/iteration) */
+};
+
+/* meaning of the README's `double t[10]` (README.md:53; slot meaning is undefined in the
+ * reference tree, defined here).  All values in seconds, accumulated over the call. */
+enum {
+    NMF_T_TOTAL = 0,        /* whole call, wall clock */
+    NMF_T_H2D = 1,          /* upload + clamp of W, H, X */
+    NMF_T_H_STEP = 2,       /* H half-steps (device time) */
+    NMF_T_W_STEP = 3,       /* W half-steps (device time) */
+    NMF_T_SUMS = 4,         /* column/row-sum normalisers */
+    NMF_T_APPLY = 5,        /* split-partial reduce + multiplicative apply */
+    NMF_T_CHECK = 6,        /* KL-divergence convergence checks */
+    NMF_T_ALLREDUCE = 7,    /* RCCL all-reduce (sharded runs) */
+    NMF_T_D2H = 8,          /* download of W, H */
+    NMF_T_SETUP = 9         /* allocation + hipGraph capture/instantiate */
+};
+
+/* ---------------------------------------------------------------------------------------
+ * update_div -- the documented drop-in surface (README.md:40-54); body = run_async,
+ * cuda/nmf.cu:76-116.  W (M x K) and H (K x N) are in/out through W.mat / H.mat (host);
+ * X (M x N) is read-only.  Inputs are clamped to >= EPS on the device copies only
+ * (cuda/nmf.cu:210-211).  Every NMF_ITER_CHECK_DEFAULT iterations the KL divergence
+ * (cuda/matrix.cu:592) is evaluated; the loop stops when (prev-cur)/prev <
+ * CONVERGE_THRESH; CONVERGE_THRESH == 0 runs exactly max_iter iterations and skips the
+ * checks unless verbose (cuda/nmf.cu:9-11).  t may be NULL.  Errors: message on stderr +
+ * exit(code), as error-check.hpp:12-17 / cuda/matrix.cu:130-134.
+ * ------------------------------------------------------------------------------------- */
+void update_div(matrix W, matrix H, matrix X, float CONVERGE_THRESH, int max_iter, double t[10],
+                int verbose);
+
+typedef struct {
+    float converge_thresh;  /* README.md:51 */
+    int   max_iter;         /* cuda/nmf.cu:10 */
+    int   iter_check;       /* cuda/nmf.cu:9; <= 0 -> NMF_ITER_CHECK_DEFAULT */
+    int   verbose;          /* README.md:54 */
+    int   path;             /* NMF_PATH_* */
+    int   use_graph;        /* 1: replay one captured hipGraph per iteration (cuda/nmf.cu:100-115) */
+    int   device;           /* HIP device ordinal, -1 = current */
+    void *stream;           /* hipStream_t to run on, NULL = library-owned stream */
+    void *comm;             /* nmf_comm* for an N-sharded run (see nmf_comm_*), NULL = single GPU */
+    int   nsplit_h;         /* 0 = auto; split count of the reduction dim in the H / W step */
+    int   nsplit_w;
+} nmf_opts;
+
+#define NMF_MAX_KL 64
+typedef struct {
+    int    iterations;          /* iterations actually executed */
+    int    n_kl;                /* KL values recorded (iteration 0 first when checks are on) */
+    double kl[NMF_MAX_KL];
+    double rel_l1;              /* sum|X-WH| / sum|X| at the last check (cuda/matrix.cu:517-518) */
+    int    path_used;
+    double t[10];
+} nmf_result;
+
+void nmf_default_opts(nmf_opts *o);
+/* same contract as update_div but returns a status instead of exiting */
+int  update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts, nmf_result *res);
+const char *nmf_status_string(int status);
+/* message of the last failing call on this thread (file:line + HIP error string) */
+const char *nmf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * matrix helpers: read_matrix / write_matrix (cuda/nmf.cu:188-259) and the Matrix
+ * constructors / destructor (cuda/matrix.cu:42-86).  File format: little-endian
+ * uint32 rows, uint32 cols, float32[rows*cols] column-major (cuda/nmf.cu:194-204).
+ * ------------------------------------------------------------------------------------- */
+int  nmf_create_matrix(matrix *A, int rows, int cols, float value);   /* host alloc + fill */
+void nmf_destroy_matrix(matrix *A);                                   /* frees mat and mat_d */
+int  nmf_read_matrix(matrix *A, const char *file);                    /* cuda/nmf.cu:188-218 (no clamp: host copy stays raw) */
+int  nmf_write_matrix(matrix A, const char *file);                    /* cuda/nmf.cu:220-259 */
+int  nmf_matrix_to_device(matrix *A);      /* allocates mat_d if NULL, H2D (cuda/matrix.cu:53-67) */
+int  nmf_matrix_from_device(matrix *A);    /* D2H into mat (cuda/nmf.cu:228-232) */
+int  nmf_matrix_free_device(matrix *A);
+
+/* ---------------------------------------------------------------------------------------
+ * Device operators, one per reference operator (cuda/matrix.cuh:41-52).  They work on
+ * the mat_d buffers of their arguments (unpadded, ld = dim[0]) on `stream` (hipStream_t,
+ * NULL = default stream), check shapes like the reference and return NMF_ERR_SHAPE where
+ * the reference exit(1)s.  Used by the NMF_PATH_UNFUSED loop and by the parity tests.
+ * ------------------------------------------------------------------------------------- */
+int nmf_matrix_multiply(matrix a, matrix b, matrix c, void *stream);      /* c = a*b    cuda/matrix.cu:97-105  */
+int nmf_matrix_multiply_AtB(matrix a, matrix b, matrix c, void *stream);  /* c = a'*b   cuda/matrix.cu:107-115 */
+int nmf_matrix_multiply_ABt(matrix a, matrix b, matrix c, void *stream);  /* c = a*b'   cuda/matrix.cu:117-125 */
+int nmf_element_multiply(matrix a, matrix b, matrix c, void *stream);     /* c = a.*b   cuda/matrix.cu:154-180 */
+int nmf_element_divide(matrix a, matrix b, matrix c, void *stream);       /* c = a./b   cuda/matrix.cu:127-152 */
+int nmf_row_divide(matrix a, matrix b, matrix c, void *stream);           /* c[i,j] = a[i,j]/b[j]  cuda/matrix.cu:203-224 */
+int nmf_col_divide(matrix a, matrix b, matrix c, void *stream);           /* c[i,j] = a[i,j]/b[i]  cuda/matrix.cu:226-250 */
+int nmf_set_epsilon(matrix a, void *stream);                              /* a<EPS -> EPS  cuda/matrix.cu:182-201 */
+int nmf_sum_cols(matrix a, matrix out, void *stream);                     /* out(1 x cols)  cuda/matrix.cu:261-377,642-687 */
+int nmf_sum_rows(matrix a, matrix out, void *stream);                     /* out(rows x 1)  cuda/matrix.cu:379-503,689-735 */
+/* KL divergence sum x(log x - log y) - x + y (reduce1d_div, cuda/matrix.cu:578-640) and
+ * sum|x-y|, sum|x| (reduce1d_diff, cuda/matrix.cu:505-576); synchronises `stream`. */
+int nmf_kl_divergence(matrix x, matrix y, double *kl, void *stream);
+int nmf_diff_norm(matrix x, matrix y, double *sum_abs_diff, double *sum_abs_x, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Resident solver: what update_div does between its H2D and D2H, exposed so that a
+ * caller (bench.py, the CLI, a multi-GPU launcher) can keep W, H, X in HBM across calls.
+ * Replaces run_async + its temporaries (cuda/nmf.cu:76-116).
+ * ------------------------------------------------------------------------------------- */
+typedef struct nmf_solver nmf_solver;
+
+/* M, N, K are the LOCAL problem dims of this process (N = this rank's column count when
+ * opts->comm is set). */
+int  nmf_solver_create(nmf_solver **s, int M, int N, int K, const nmf_opts *opts);
+void nmf_solver_destroy(nmf_solver *s);
+/* host -> device (clamped to EPS like read_matrix, cuda/nmf.cu:211); any pointer may be NULL to skip */
+int  nmf_solver_upload(nmf_solver *s, const float *W, const float *H, const float *X);
+/* same from unpadded device buffers (ld = rows) */
+int  nmf_solver_upload_device(nmf_solver *s, const float *W_d, const float *H_d, const float *X_d);
+int  nmf_solver_download(nmf_solver *s, float *W, float *H);
+/* enqueue `iters` iterations (H half-step then W half-step each, cuda/nmf.cu:108-109) on the
+ * solver's stream; does not synchronise. */
+int  nmf_solver_iterate(nmf_solver *s, int iters);
+/* the two half-steps separately (cuda/nmf.cu:118-146 / 148-176) */
+int  nmf_solver_update_h(nmf_solver *s);
+int  nmf_solver_update_w(nmf_solver *s);
+/* KL(X || W*H) and rel-L1 of the current state; synchronises.  In a sharded run the values
+ * are summed over ranks. */
+int  nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1);
+/* full loop with convergence logic; fills res (may be NULL) */
+int  nmf_solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, int verbose, nmf_result *res);
+int  nmf_solver_sync(nmf_solver *s);
+/* time one piece in isolation: which = NMF_T_H_STEP / NMF_T_W_STEP / NMF_T_SUMS / NMF_T_APPLY /
+ * NMF_T_CHECK; runs it `reps` times between two hipEvents on the solver's stream and returns the
+ * average milliseconds per launch of the dominant kernel of that piece. */
+int  nmf_solver_time_piece(nmf_solver *s, int which, int reps, double *ms_per_launch);
+/* sharded runs where the caller performs the all-reduce itself (e.g. torch.distributed):
+ * w_partial leaves sum_g-local [Z*H' (M*K floats) ; rowsum(H) (K floats)] in a device buffer
+ * (pointer/count returned by nmf_solver_partial_buffer); after reducing it in place across ranks
+ * call w_apply. */
+int  nmf_solver_w_partial(nmf_solver *s);
+int  nmf_solver_w_apply(nmf_solver *s);
+int  nmf_solver_partial_buffer(nmf_solver *s, float **dev_ptr, size_t *count);
+/* make the solver use a caller-owned device buffer of `count` floats (>= the count reported above) as
+ * its partial buffer, e.g. the storage of a torch tensor that torch.distributed will all-reduce */
+int  nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size_t count);
+int  nmf_solver_path(const nmf_solver *s);
+void *nmf_solver_stream(nmf_solver *s);
+
+/* ---------------------------------------------------------------------------------------
+ * RCCL communicator for N-sharded runs (new: the reference is single-GPU).  One process
+ * per GPU; rank 0 creates the id, the launcher broadcasts its 128 bytes (e.g. with
+ * torch.distributed), every rank calls nmf_comm_init_rank.
+ * ------------------------------------------------------------------------------------- */
+typedef struct nmf_comm nmf_comm;
+#define NMF_COMM_ID_BYTES 128
+int  nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]);
+int  nmf_comm_init_rank(nmf_comm **c, const unsigned char id[NMF_COMM_ID_BYTES], int rank, int nranks);
+void nmf_comm_destroy(nmf_comm *c);
+
+/* device queries used by bench/tests */
+int  nmf_device_count(void);
+int  nmf_device_name(int device, char *buf, int buflen);
+const char *nmf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMF_MI355X_H */

@@ -1,0 +1,847 @@
+// nmf_host.cpp -- host side of libnmf_mi355x.so: the resident solver, the update_div loop with
+// its convergence contract, hipGraph capture/replay, timers, and the per-operator C entry points.
+//
+// Mirrors (does not translate) the reference's host logic: run_async / update_h / update_w
+// (cuda/nmf.cu:76-176) and the operator wrappers of cuda/matrix.cu:97-260.
+#include "../../include/nmf_mi355x.h"
+#include "nmf_comm.h"
+#include "nmf_kernels.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace nmf;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *nmf_last_error(void) { return g_err; }
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            set_err("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));                 \
+            return NMF_ERR_HIP;                                                                           \
+        }                                                                                                 \
+    } while (0)
+#define NMFCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        int s_ = (expr);                                                                                  \
+        if (s_ != NMF_OK) return s_;                                                                      \
+    } while (0)
+
+extern "C" const char *nmf_status_string(int st) {
+    switch (st) {
+        case NMF_OK: return "ok";
+        case NMF_ERR_ARG: return "invalid argument";
+        case NMF_ERR_SHAPE: return "dimensions do not agree";
+        case NMF_ERR_HIP: return "HIP runtime error";
+        case NMF_ERR_IO: return "file I/O error";
+        case NMF_ERR_NOMEM: return "out of memory";
+        case NMF_ERR_COMM: return "RCCL error";
+        case NMF_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+extern "C" const char *nmf_version(void) { return "nmf_mi355x 0.1 (gfx950)"; }
+
+extern "C" int nmf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int nmf_device_name(int device, char *buf, int buflen) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return NMF_OK;
+}
+
+extern "C" void nmf_default_opts(nmf_opts *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->converge_thresh = 0.f;
+    o->max_iter = 200;                         // cuda/nmf.cu:10
+    o->iter_check = NMF_ITER_CHECK_DEFAULT;    // cuda/nmf.cu:9
+    o->verbose = 0;
+    o->path = NMF_PATH_AUTO;
+    o->use_graph = 1;
+    o->device = -1;
+    o->stream = nullptr;
+    o->comm = nullptr;
+    o->nsplit_h = 0;
+    o->nsplit_w = 0;
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------ solver
+struct nmf_solver {
+    int M = 0, N = 0, K = 0;       // logical (local) dims
+    int Mp = 0, Np = 0, Kp = 0;    // padded device dims
+    int path = NMF_PATH_FUSED;
+    int use_graph = 1;
+    int nsplit_h = 1, nsplit_w = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
+    bool external_reduce = false;  // sharded, caller reduces the partial buffer
+    // device state
+    float *W = nullptr, *H = nullptr, *X = nullptr;
+    float *normW = nullptr, *normH = nullptr, *rowpart = nullptr;
+    float *partials = nullptr;     // split slabs
+    float *psum = nullptr;         // Mp*Kp + Kp floats: [sum_g Z*H' ; rowsum(H)] (all-reduce operand)
+    float *psum_owned = nullptr;   // the allocation behind psum unless the caller supplied one
+    double *chk_part = nullptr, *chk_out = nullptr, *chk_host = nullptr;
+    int chk_groups = 0;
+    float *Z = nullptr, *WtZ = nullptr, *ZHt = nullptr;   // unfused temporaries (cuda/nmf.cu:94-96)
+    float *staging = nullptr;      // unpadded upload/download staging (max of the three matrices)
+    size_t staging_count = 0;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ready = false;
+    // piece timing (eager, hipEvent pairs)
+    bool timing = false;
+    struct Ev { int which; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    double t_setup = 0.0;
+};
+
+static int dev_alloc(float **p, size_t count) {
+    HIPCHK(hipMalloc((void **)p, count * sizeof(float)));
+    return NMF_OK;
+}
+
+static int pick_nsplit(int q_extent, int p_extent) {
+    // workgroups per split-less launch = ceil(Q/128); aim for >= 512 workgroups (2 per CU),
+    // keep >= 2 chunks of 32 per split.
+    const int nq = (q_extent + 127) / 128;
+    if (nq >= 256) return 1;
+    int ns = (512 + nq - 1) / nq;
+    const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
+    if (ns > max_ns) ns = max_ns;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nmf_opts *opts_in) {
+    if (!out || M <= 0 || N <= 0 || K <= 0) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
+    nmf_opts o;
+    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    const double t0 = now_s();
+    if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
+    nmf_solver *s = new nmf_solver();
+    s->M = M; s->N = N; s->K = K;
+    s->Mp = pad32(M); s->Np = pad32(N);
+    int path = o.path;
+    if (path == NMF_PATH_AUTO) path = (pad32(K) <= 32 * kMaxFusedKT) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
+    if (path == NMF_PATH_FUSED) {
+        if (pad32(K) > 32 * kMaxFusedKT) { delete s; set_err("fused path supports K <= %d", 32 * kMaxFusedKT); return NMF_ERR_UNSUPPORTED; }
+        int kt = pad32(K) / 32, ktp = 1;
+        while (ktp < kt) ktp <<= 1;     // instantiated tile counts: 1, 2, 4, 8
+        s->Kp = ktp * 32;
+    } else {
+        s->Kp = pad32(K);
+    }
+    s->path = path;
+    s->use_graph = o.use_graph;
+    s->comm = (nmf_comm *)o.comm;
+    if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+
+    const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
+    NMFCHK(dev_alloc(&s->W, mk));
+    NMFCHK(dev_alloc(&s->H, kn));
+    NMFCHK(dev_alloc(&s->X, mn));
+    HIPCHK(hipMemsetAsync(s->W, 0, mk * sizeof(float), s->stream));
+    HIPCHK(hipMemsetAsync(s->H, 0, kn * sizeof(float), s->stream));
+    HIPCHK(hipMemsetAsync(s->X, 0, mn * sizeof(float), s->stream));
+    NMFCHK(dev_alloc(&s->normW, (size_t)s->Kp));
+    NMFCHK(dev_alloc(&s->normH, (size_t)s->Kp));
+    NMFCHK(dev_alloc(&s->rowpart, (size_t)row_sum_blocks(s->Np) * s->Kp));
+    NMFCHK(dev_alloc(&s->psum_owned, mk + (size_t)s->Kp));
+    s->psum = s->psum_owned;
+    if (path == NMF_PATH_FUSED) {
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np);
+        if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
+        if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
+        size_t pc = 0;
+        if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
+        if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
+        NMFCHK(dev_alloc(&s->partials, pc));
+        s->chk_groups = check_num_groups(s->Np);
+    } else {
+        NMFCHK(dev_alloc(&s->Z, mn));
+        NMFCHK(dev_alloc(&s->WtZ, kn));
+        NMFCHK(dev_alloc(&s->ZHt, mk));
+        s->chk_groups = reduce_num_groups(mn);
+    }
+    HIPCHK(hipMalloc((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups));
+    HIPCHK(hipMalloc((void **)&s->chk_out, sizeof(double) * 3));
+    HIPCHK(hipHostMalloc((void **)&s->chk_host, sizeof(double) * 3, hipHostMallocDefault));
+    s->staging_count = (size_t)M * N;
+    if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
+    if ((size_t)K * N > s->staging_count) s->staging_count = (size_t)K * N;
+    NMFCHK(dev_alloc(&s->staging, s->staging_count));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->t_setup = now_s() - t0;
+    *out = s;
+    return NMF_OK;
+}
+
+extern "C" void nmf_solver_destroy(nmf_solver *s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s->stream);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    float *bufs[] = {s->W, s->H, s->X, s->normW, s->normH, s->rowpart, s->partials, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
+    for (float *b : bufs) if (b) (void)hipFree(b);
+    if (s->chk_part) (void)hipFree(s->chk_part);
+    if (s->chk_out) (void)hipFree(s->chk_out);
+    if (s->chk_host) (void)hipHostFree(s->chk_host);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int nmf_solver_path(const nmf_solver *s) { return s ? s->path : 0; }
+extern "C" void *nmf_solver_stream(nmf_solver *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" int nmf_solver_sync(nmf_solver *s) {
+    if (!s) return NMF_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NMF_OK;
+}
+
+// upload one matrix: (host|device) unpadded -> padded + clamp (read_matrix, cuda/nmf.cu:208-211)
+static int upload_one(nmf_solver *s, float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool host) {
+    if (!src) return NMF_OK;
+    const float *d = src;
+    if (host) {
+        HIPCHK(hipMemcpyAsync(s->staging, src, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        d = s->staging;
+    }
+    HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, s->stream));
+    if (host) HIPCHK(hipStreamSynchronize(s->stream));   // staging is reused by the next matrix
+    return NMF_OK;
+}
+
+extern "C" int nmf_solver_upload(nmf_solver *s, const float *W, const float *H, const float *X) {
+    if (!s) return NMF_ERR_ARG;
+    NMFCHK(upload_one(s, s->W, s->Mp, s->Kp, W, s->M, s->K, true));
+    NMFCHK(upload_one(s, s->H, s->Kp, s->Np, H, s->K, s->N, true));
+    NMFCHK(upload_one(s, s->X, s->Mp, s->Np, X, s->M, s->N, true));
+    return NMF_OK;
+}
+extern "C" int nmf_solver_upload_device(nmf_solver *s, const float *W, const float *H, const float *X) {
+    if (!s) return NMF_ERR_ARG;
+    NMFCHK(upload_one(s, s->W, s->Mp, s->Kp, W, s->M, s->K, false));
+    NMFCHK(upload_one(s, s->H, s->Kp, s->Np, H, s->K, s->N, false));
+    NMFCHK(upload_one(s, s->X, s->Mp, s->Np, X, s->M, s->N, false));
+    return NMF_OK;
+}
+
+// write_matrix strips the padding (cuda/nmf.cu:228-231)
+extern "C" int nmf_solver_download(nmf_solver *s, float *W, float *H) {
+    if (!s) return NMF_ERR_ARG;
+    if (W) {
+        HIPCHK(launch_unpad_copy(s->staging, s->M, s->K, s->W, s->Mp, s->stream));
+        HIPCHK(hipMemcpyAsync(W, s->staging, (size_t)s->M * s->K * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    if (H) {
+        HIPCHK(launch_unpad_copy(s->staging, s->K, s->N, s->H, s->Kp, s->stream));
+        HIPCHK(hipMemcpyAsync(H, s->staging, (size_t)s->K * s->N * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return NMF_OK;
+}
+
+// --------------------------------------------------------------------- piece timing
+struct PieceScope {
+    nmf_solver *s; int idx = -1;
+    PieceScope(nmf_solver *s_, int which) : s(s_) {
+        if (!s->timing) return;
+        nmf_solver::Ev e; e.which = which;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        (void)hipEventRecord(e.a, s->stream);
+        s->events.push_back(e);
+        idx = (int)s->events.size() - 1;
+    }
+    ~PieceScope() { if (idx >= 0) (void)hipEventRecord(s->events[idx].b, s->stream); }
+};
+
+static int collect_timing(nmf_solver *s, double t[10]) {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (auto &e : s->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && t) t[e.which] += (double)ms * 1e-3;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    s->events.clear();
+    return NMF_OK;
+}
+
+// --------------------------------------------------------------------- half-steps
+static FusedArgs fused_args(nmf_solver *s) {
+    FusedArgs a;
+    a.W = s->W; a.H = s->H; a.X = s->X;
+    a.U_out = nullptr; a.partials = s->partials; a.norm = nullptr;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0;
+    return a;
+}
+
+// cuda/nmf.cu:118-146
+static int enqueue_update_h(nmf_solver *s) {
+    hipStream_t st = s->stream;
+    if (s->path == NMF_PATH_FUSED) {
+        { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }
+        FusedArgs a = fused_args(s);
+        a.nsplit = s->nsplit_h;
+        if (s->nsplit_h == 1) {
+            a.U_out = s->H; a.norm = s->normW; a.partial = 0;
+            PieceScope p(s, NMF_T_H_STEP);
+            HIPCHK(launch_fused_step(a, false, st));
+        } else {
+            a.partial = 1;
+            { PieceScope p(s, NMF_T_H_STEP); HIPCHK(launch_fused_step(a, false, st)); }
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_apply_partials(s->H, s->partials, s->nsplit_h, s->normW, s->Mp, s->Np, s->Kp, false, st));
+        }
+        return NMF_OK;
+    }
+    // unfused: operator-for-operator twin of cuda/nmf.cu:125-145
+    const size_t mn = (size_t)s->Mp * s->Np, kn = (size_t)s->Kp * s->Np;
+    {
+        PieceScope p(s, NMF_T_H_STEP);
+        HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));   // nmf.cu:125
+        HIPCHK(launch_set_epsilon(s->Z, mn, st));                                                       // nmf.cu:128
+        HIPCHK(launch_vec_div(s->X, s->Z, s->Z, mn, st));                                               // nmf.cu:131
+    }
+    { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }   // nmf.cu:134-135
+    {
+        PieceScope p(s, NMF_T_H_STEP);
+        HIPCHK(launch_gemm(GEMM_TN, s->Kp, s->Np, s->Mp, s->W, s->Mp, s->Z, s->Mp, s->WtZ, s->Kp, st)); // nmf.cu:138
+    }
+    {
+        PieceScope p(s, NMF_T_APPLY);
+        HIPCHK(launch_col_div(s->WtZ, s->normW, s->WtZ, s->Kp, s->Np, s->Kp, st));                      // nmf.cu:142
+        HIPCHK(launch_vec_mul(s->H, s->WtZ, s->H, kn, st));                                             // nmf.cu:145
+    }
+    return NMF_OK;
+}
+
+// first half of cuda/nmf.cu:148-176: leaves [Z*H' ; rowsum(H)] of the local columns in psum
+static int enqueue_w_partial(nmf_solver *s) {
+    hipStream_t st = s->stream;
+    const size_t mk = (size_t)s->Mp * s->Kp, mn = (size_t)s->Mp * s->Np;
+    { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->psum + mk, /*clamp=*/false, st)); }
+    if (s->path == NMF_PATH_FUSED) {
+        FusedArgs a = fused_args(s);
+        a.nsplit = s->nsplit_w; a.partial = 1;
+        a.partials = (s->nsplit_w == 1) ? s->psum : s->partials;
+        { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
+        if (s->nsplit_w > 1) { PieceScope p(s, NMF_T_APPLY); HIPCHK(launch_sum_partials(s->psum, s->partials, s->nsplit_w, mk, st)); }
+    } else {
+        PieceScope p(s, NMF_T_W_STEP);
+        HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
+        HIPCHK(launch_set_epsilon(s->Z, mn, st));
+        HIPCHK(launch_vec_div(s->X, s->Z, s->Z, mn, st));
+        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->psum, s->Mp, st));
+    }
+    return NMF_OK;
+}
+
+static int enqueue_w_apply(nmf_solver *s) {
+    const size_t mk = (size_t)s->Mp * s->Kp;
+    PieceScope p(s, NMF_T_APPLY);
+    HIPCHK(launch_apply_w(s->W, s->psum, s->psum + mk, s->Mp, s->Kp, s->stream));
+    return NMF_OK;
+}
+
+// cuda/nmf.cu:148-176
+static int enqueue_update_w(nmf_solver *s) {
+    hipStream_t st = s->stream;
+    if (s->comm) {   // N-sharded: one all-reduce of (Mp*Kp + Kp) floats per iteration
+        const size_t mk = (size_t)s->Mp * s->Kp;
+        NMFCHK(enqueue_w_partial(s));
+        { PieceScope p(s, NMF_T_ALLREDUCE); NMFCHK(nmf_comm_allreduce_f32(s->comm, s->psum, mk + (size_t)s->Kp, st)); }
+        return enqueue_w_apply(s);
+    }
+    if (s->path == NMF_PATH_FUSED) {
+        { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
+        FusedArgs a = fused_args(s);
+        a.nsplit = s->nsplit_w;
+        if (s->nsplit_w == 1) {
+            a.U_out = s->W; a.norm = s->normH; a.partial = 0;
+            PieceScope p(s, NMF_T_W_STEP);
+            HIPCHK(launch_fused_step(a, true, st));
+        } else {
+            a.partial = 1;
+            { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, s->normH, s->Mp, s->Np, s->Kp, true, st));
+        }
+        return NMF_OK;
+    }
+    const size_t mn = (size_t)s->Mp * s->Np, mk = (size_t)s->Mp * s->Kp;
+    {
+        PieceScope p(s, NMF_T_W_STEP);
+        HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));   // nmf.cu:155
+        HIPCHK(launch_set_epsilon(s->Z, mn, st));                                                       // nmf.cu:158
+        HIPCHK(launch_vec_div(s->X, s->Z, s->Z, mn, st));                                               // nmf.cu:161
+    }
+    { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }   // nmf.cu:164-165
+    {
+        PieceScope p(s, NMF_T_W_STEP);
+        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->ZHt, s->Mp, st)); // nmf.cu:168
+    }
+    {
+        PieceScope p(s, NMF_T_APPLY);
+        HIPCHK(launch_row_div(s->ZHt, s->normH, s->ZHt, s->Mp, s->Kp, s->Mp, st));                      // nmf.cu:172
+        HIPCHK(launch_vec_mul(s->W, s->ZHt, s->W, mk, st));                                             // nmf.cu:175
+    }
+    return NMF_OK;
+}
+
+extern "C" int nmf_solver_update_h(nmf_solver *s) { return s ? enqueue_update_h(s) : NMF_ERR_ARG; }
+extern "C" int nmf_solver_update_w(nmf_solver *s) {
+    if (!s) return NMF_ERR_ARG;
+    if (s->external_reduce) { set_err("solver is in external-reduce mode: use w_partial / w_apply"); return NMF_ERR_UNSUPPORTED; }
+    return enqueue_update_w(s);
+}
+extern "C" int nmf_solver_w_partial(nmf_solver *s) {
+    if (!s) return NMF_ERR_ARG;
+    s->external_reduce = true;
+    return enqueue_w_partial(s);
+}
+extern "C" int nmf_solver_w_apply(nmf_solver *s) { return s ? enqueue_w_apply(s) : NMF_ERR_ARG; }
+extern "C" int nmf_solver_partial_buffer(nmf_solver *s, float **dev_ptr, size_t *count) {
+    if (!s || !dev_ptr || !count) return NMF_ERR_ARG;
+    *dev_ptr = s->psum;
+    *count = (size_t)s->Mp * s->Kp + (size_t)s->Kp;
+    return NMF_OK;
+}
+
+extern "C" int nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size_t count) {
+    if (!s || !dev_ptr) return NMF_ERR_ARG;
+    if (count < (size_t)s->Mp * s->Kp + (size_t)s->Kp) { set_err("partial buffer too small"); return NMF_ERR_ARG; }
+    if (s->graph_ready) { set_err("partial buffer must be set before the first iterate()"); return NMF_ERR_UNSUPPORTED; }
+    s->psum = dev_ptr;
+    return NMF_OK;
+}
+
+// cuda/nmf.cu:100-115: capture one iteration, replay it
+static int ensure_graph(nmf_solver *s) {
+    if (s->graph_ready) return NMF_OK;
+    const double t0 = now_s();
+    HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    int st = enqueue_update_h(s);
+    if (st == NMF_OK) st = enqueue_update_w(s);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (st != NMF_OK) { if (g) (void)hipGraphDestroy(g); return st; }
+    if (e != hipSuccess) { set_err("hipStreamEndCapture: %s", hipGetErrorString(e)); return NMF_ERR_HIP; }
+    s->graph = g;
+    HIPCHK(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+    s->graph_ready = true;
+    s->t_setup += now_s() - t0;
+    return NMF_OK;
+}
+
+extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
+    if (!s || iters < 0) return NMF_ERR_ARG;
+    if (s->external_reduce) { set_err("solver is in external-reduce mode"); return NMF_ERR_UNSUPPORTED; }
+    if (s->use_graph && !s->timing) {
+        int st = ensure_graph(s);
+        if (st == NMF_OK) {
+            for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));
+            return NMF_OK;
+        }
+        // capture unavailable (e.g. a collective that cannot be captured): fall back to eager launches
+        fprintf(stderr, "nmf: hipGraph capture failed (%s); running eagerly\n", g_err);
+        (void)hipGetLastError();
+        s->use_graph = 0;
+    }
+    for (int i = 0; i < iters; ++i) {
+        NMFCHK(enqueue_update_h(s));
+        NMFCHK(enqueue_update_w(s));
+    }
+    return NMF_OK;
+}
+
+// KL / rel-L1 of the current state (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640)
+extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
+    if (!s) return NMF_ERR_ARG;
+    hipStream_t st = s->stream;
+    {
+        PieceScope p(s, NMF_T_CHECK);
+        if (s->path == NMF_PATH_FUSED) {
+            HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+        } else {
+            const size_t mn = (size_t)s->Mp * s->Np;
+            HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
+            HIPCHK(launch_set_epsilon(s->Z, mn, st));
+            HIPCHK(launch_kl_reduce(s->X, s->Z, mn, s->chk_part, st));
+        }
+        HIPCHK(launch_check_final(s->chk_part, s->chk_groups, s->chk_out, st));
+        if (s->comm) NMFCHK(nmf_comm_allreduce_f64(s->comm, s->chk_out, 3, st));
+    }
+    HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (kl) *kl = s->chk_host[0];
+    if (rel_l1) *rel_l1 = (s->chk_host[2] > 0.0) ? s->chk_host[1] / s->chk_host[2] : 0.0;
+    return NMF_OK;
+}
+
+// The loop: cuda/nmf.cu:113-115 plus the README.md:40-54 convergence contract.
+static int solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, int verbose, nmf_result *res, bool timed) {
+    if (!s || max_iter < 0) return NMF_ERR_ARG;
+    if (iter_check <= 0) iter_check = NMF_ITER_CHECK_DEFAULT;
+    const bool checks = (thresh > 0.f) || verbose;
+    s->timing = timed;
+    double prev = 0.0, rl1 = 0.0;
+    int nkl = 0;
+    if (res) { res->n_kl = 0; res->rel_l1 = 0.0; res->path_used = s->path; }
+    if (checks) {
+        NMFCHK(nmf_solver_check(s, &prev, &rl1));
+        if (res && nkl < NMF_MAX_KL) res->kl[nkl] = prev;
+        nkl++;
+        if (verbose) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", 0, prev, rl1);
+    }
+    int it = 0;
+    while (it < max_iter) {
+        int n = max_iter - it;
+        if (checks) { const int to_check = iter_check - (it % iter_check); if (to_check < n) n = to_check; }
+        NMFCHK(nmf_solver_iterate(s, n));
+        it += n;
+        if (checks && (it % iter_check) == 0) {
+            double cur = 0.0;
+            NMFCHK(nmf_solver_check(s, &cur, &rl1));
+            if (res && nkl < NMF_MAX_KL) res->kl[nkl] = cur;
+            nkl++;
+            if (verbose) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", it, cur, rl1, (prev - cur) / prev);
+            const bool stop = thresh > 0.f && (prev - cur) / prev < (double)thresh;   // README.md:51
+            prev = cur;
+            if (stop) break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());   // the reference never polls launch errors; we do
+    if (res) { res->iterations = it; res->n_kl = nkl < NMF_MAX_KL ? nkl : NMF_MAX_KL; res->rel_l1 = rl1; }
+    if (timed) NMFCHK(collect_timing(s, res ? res->t : nullptr));
+    s->timing = false;
+    return NMF_OK;
+}
+
+extern "C" int nmf_solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, int verbose, nmf_result *res) {
+    if (res) memset(res->t, 0, sizeof res->t);
+    return solver_run(s, thresh, max_iter, iter_check, verbose, res, false);
+}
+
+extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double *ms_per_launch) {
+    if (!s || reps <= 0 || !ms_per_launch) return NMF_ERR_ARG;
+    hipStream_t st = s->stream;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    FusedArgs fa = fused_args(s);
+    const size_t mk = (size_t)s->Mp * s->Kp;
+    // normalisers must be valid before timing an in-place fused step
+    HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st));
+    HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st));
+    HIPCHK(hipEventRecord(a, st));
+    for (int i = 0; i < reps; ++i) {
+        switch (which) {
+            case NMF_T_H_STEP:
+                if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
+                fa.nsplit = s->nsplit_h; fa.partial = s->nsplit_h > 1; fa.U_out = s->H; fa.norm = s->normW; fa.partials = s->partials;
+                HIPCHK(launch_fused_step(fa, false, st));
+                break;
+            case NMF_T_W_STEP:
+                if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
+                fa.nsplit = s->nsplit_w; fa.partial = s->nsplit_w > 1; fa.U_out = s->W; fa.norm = s->normH; fa.partials = s->partials;
+                HIPCHK(launch_fused_step(fa, true, st));
+                break;
+            case NMF_T_SUMS:
+                HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st));
+                HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st));
+                break;
+            case NMF_T_APPLY:
+                HIPCHK(launch_sum_partials(s->psum, s->partials ? s->partials : s->psum, s->partials ? s->nsplit_w : 1, mk, st));
+                break;
+            case NMF_T_CHECK:
+                if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
+                HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+                break;
+            default:
+                return NMF_ERR_ARG;
+        }
+    }
+    HIPCHK(hipEventRecord(b, st));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / reps;
+    return NMF_OK;
+}
+
+// ------------------------------------------------------------------------------ update_div
+extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_in, nmf_result *res) {
+    const double t_begin = now_s();
+    nmf_opts o;
+    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    if ((!W.mat && !W.mat_d) || (!H.mat && !H.mat_d) || (!X.mat && !X.mat_d)) { set_err("update_div: NULL matrix data"); return NMF_ERR_ARG; }
+    const int M = W.dim[0], K = W.dim[1], N = H.dim[1];
+    if (M <= 0 || K <= 0 || N <= 0) { set_err("update_div: non-positive dimension"); return NMF_ERR_ARG; }
+    if (H.dim[0] != K || X.dim[0] != M || X.dim[1] != N) {
+        set_err("update_div: dimensions do not agree: W %dx%d, H %dx%d, X %dx%d", W.dim[0], W.dim[1], H.dim[0], H.dim[1], X.dim[0], X.dim[1]);
+        return NMF_ERR_SHAPE;
+    }
+    nmf_result local;
+    if (!res) res = &local;
+    memset(res, 0, sizeof *res);
+    nmf_solver *s = nullptr;
+    NMFCHK(nmf_solver_create(&s, M, N, K, &o));
+    int st = NMF_OK;
+    double t0 = now_s();
+    // host data wins when present; otherwise the caller's device buffers are the source
+    if (st == NMF_OK) st = W.mat ? nmf_solver_upload(s, W.mat, nullptr, nullptr) : nmf_solver_upload_device(s, W.mat_d, nullptr, nullptr);
+    if (st == NMF_OK) st = H.mat ? nmf_solver_upload(s, nullptr, H.mat, nullptr) : nmf_solver_upload_device(s, nullptr, H.mat_d, nullptr);
+    if (st == NMF_OK) st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
+    if (st == NMF_OK) st = nmf_solver_sync(s);
+    res->t[NMF_T_H2D] = now_s() - t0;
+    // use_graph == 0 -> eager launches, each piece bracketed by hipEvents (fills t[2..7])
+    const bool timed = (o.use_graph == 0);
+    if (st == NMF_OK) st = solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, res, timed);
+    t0 = now_s();
+    if (st == NMF_OK) {
+        if (W.mat) st = nmf_solver_download(s, W.mat, nullptr);
+        if (st == NMF_OK && H.mat) st = nmf_solver_download(s, nullptr, H.mat);
+        // keep caller-provided device mirrors coherent (unpadded layout)
+        if (st == NMF_OK && W.mat_d) {
+            if (launch_unpad_copy(W.mat_d, M, K, s->W, s->Mp, s->stream) != hipSuccess) st = NMF_ERR_HIP;
+        }
+        if (st == NMF_OK && H.mat_d) {
+            if (launch_unpad_copy(H.mat_d, K, N, s->H, s->Kp, s->stream) != hipSuccess) st = NMF_ERR_HIP;
+        }
+        if (st == NMF_OK) st = nmf_solver_sync(s);
+    }
+    res->t[NMF_T_D2H] = now_s() - t0;
+    res->t[NMF_T_SETUP] = s->t_setup;
+    nmf_solver_destroy(s);
+    res->t[NMF_T_TOTAL] = now_s() - t_begin;
+    return st;
+}
+
+// README.md:40-46.  void + exit on error like the reference (error-check.hpp:12-17).
+extern "C" void update_div(matrix W, matrix H, matrix X, float CONVERGE_THRESH, int max_iter, double t[10], int verbose) {
+    nmf_opts o;
+    nmf_default_opts(&o);
+    o.converge_thresh = CONVERGE_THRESH;
+    o.max_iter = max_iter;
+    o.verbose = verbose;
+    o.use_graph = (t == nullptr) ? 1 : 0;   // timers requested: eager launches with per-piece hipEvents
+    nmf_result res;
+    const int st = update_div_ex(W, H, X, &o, &res);
+    if (st != NMF_OK) {
+        fprintf(stderr, "update_div: %s (%s)\n", nmf_status_string(st), nmf_last_error());
+        exit(st);
+    }
+    if (t) for (int i = 0; i < 10; ++i) t[i] = res.t[i];
+    if (verbose) printf("update_div: %d iterations, %.3f s total\n", res.iterations, res.t[NMF_T_TOTAL]);
+}
+
+// ------------------------------------------------------------------------------ operators
+static int need_dev(const matrix &a, const char *who) {
+    if (!a.mat_d) { set_err("%s: matrix has no device buffer (mat_d == NULL)", who); return NMF_ERR_ARG; }
+    if (a.dim[0] <= 0 || a.dim[1] <= 0) { set_err("%s: non-positive dimension", who); return NMF_ERR_ARG; }
+    return NMF_OK;
+}
+static int shape_err(const char *who) {
+    set_err("%s: dimensions do not agree", who);
+    return NMF_ERR_SHAPE;
+}
+
+extern "C" int nmf_matrix_multiply(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "matrix_multiply")); NMFCHK(need_dev(b, "matrix_multiply")); NMFCHK(need_dev(c, "matrix_multiply"));
+    if (a.dim[1] != b.dim[0] || c.dim[0] != a.dim[0] || c.dim[1] != b.dim[1]) return shape_err("matrix_multiply");
+    HIPCHK(launch_gemm(GEMM_NN, c.dim[0], c.dim[1], a.dim[1], a.mat_d, a.dim[0], b.mat_d, b.dim[0], c.mat_d, c.dim[0], (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_matrix_multiply_AtB(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "matrix_multiply_AtB")); NMFCHK(need_dev(b, "matrix_multiply_AtB")); NMFCHK(need_dev(c, "matrix_multiply_AtB"));
+    if (a.dim[0] != b.dim[0] || c.dim[0] != a.dim[1] || c.dim[1] != b.dim[1]) return shape_err("matrix_multiply_AtB");
+    HIPCHK(launch_gemm(GEMM_TN, c.dim[0], c.dim[1], a.dim[0], a.mat_d, a.dim[0], b.mat_d, b.dim[0], c.mat_d, c.dim[0], (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_matrix_multiply_ABt(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "matrix_multiply_ABt")); NMFCHK(need_dev(b, "matrix_multiply_ABt")); NMFCHK(need_dev(c, "matrix_multiply_ABt"));
+    if (a.dim[1] != b.dim[1] || c.dim[0] != a.dim[0] || c.dim[1] != b.dim[0]) return shape_err("matrix_multiply_ABt");
+    HIPCHK(launch_gemm(GEMM_NT, c.dim[0], c.dim[1], a.dim[1], a.mat_d, a.dim[0], b.mat_d, b.dim[0], c.mat_d, c.dim[0], (hipStream_t)stream));
+    return NMF_OK;
+}
+static bool same_shape(const matrix &a, const matrix &b) { return a.dim[0] == b.dim[0] && a.dim[1] == b.dim[1]; }
+
+extern "C" int nmf_element_multiply(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "element_multiply")); NMFCHK(need_dev(b, "element_multiply")); NMFCHK(need_dev(c, "element_multiply"));
+    if (!same_shape(a, b) || !same_shape(a, c)) return shape_err("element_multiply");
+    HIPCHK(launch_vec_mul(a.mat_d, b.mat_d, c.mat_d, (size_t)a.dim[0] * a.dim[1], (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_element_divide(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "element_divide")); NMFCHK(need_dev(b, "element_divide")); NMFCHK(need_dev(c, "element_divide"));
+    if (!same_shape(a, b) || !same_shape(a, c)) return shape_err("element_divide");
+    HIPCHK(launch_vec_div(a.mat_d, b.mat_d, c.mat_d, (size_t)a.dim[0] * a.dim[1], (hipStream_t)stream));
+    return NMF_OK;
+}
+// every row of a divided element-wise by the vector b (length = a's column count): cuda/matrix.cu:203-224
+extern "C" int nmf_row_divide(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "row_divide")); NMFCHK(need_dev(b, "row_divide")); NMFCHK(need_dev(c, "row_divide"));
+    if (a.dim[1] != b.dim[0] || b.dim[1] != 1 || !same_shape(a, c)) return shape_err("row_divide");
+    HIPCHK(launch_row_div(a.mat_d, b.mat_d, c.mat_d, a.dim[0], a.dim[1], a.dim[0], (hipStream_t)stream));
+    return NMF_OK;
+}
+// every column of a divided element-wise by the vector b (length = a's row count): cuda/matrix.cu:226-250
+extern "C" int nmf_col_divide(matrix a, matrix b, matrix c, void *stream) {
+    NMFCHK(need_dev(a, "col_divide")); NMFCHK(need_dev(b, "col_divide")); NMFCHK(need_dev(c, "col_divide"));
+    if (a.dim[0] != b.dim[1] || b.dim[0] != 1 || !same_shape(a, c)) return shape_err("col_divide");
+    HIPCHK(launch_col_div(a.mat_d, b.mat_d, c.mat_d, a.dim[0], a.dim[1], a.dim[0], (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_set_epsilon(matrix a, void *stream) {
+    NMFCHK(need_dev(a, "set_epsilon"));
+    HIPCHK(launch_set_epsilon(a.mat_d, (size_t)a.dim[0] * a.dim[1], (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_sum_cols(matrix a, matrix out, void *stream) {
+    NMFCHK(need_dev(a, "sum_cols")); NMFCHK(need_dev(out, "sum_cols"));
+    if (out.dim[0] != 1 || out.dim[1] != a.dim[1]) return shape_err("sum_cols");   // cuda/matrix.cu:272-275
+    HIPCHK(launch_col_sums(a.mat_d, a.dim[0], a.dim[1], a.dim[0], out.mat_d, false, (hipStream_t)stream));
+    return NMF_OK;
+}
+extern "C" int nmf_sum_rows(matrix a, matrix out, void *stream) {
+    NMFCHK(need_dev(a, "sum_rows")); NMFCHK(need_dev(out, "sum_rows"));
+    if (out.dim[1] != 1 || out.dim[0] != a.dim[0]) return shape_err("sum_rows");   // cuda/matrix.cu:391-394
+    float *part = nullptr;
+    HIPCHK(hipMalloc((void **)&part, sizeof(float) * (size_t)row_sum_blocks(a.dim[1]) * a.dim[0]));
+    hipError_t e = launch_row_sums(a.mat_d, a.dim[0], a.dim[1], a.dim[0], part, out.mat_d, false, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(part);
+    HIPCHK(e);
+    return NMF_OK;
+}
+
+static int reduce3(matrix x, matrix y, double out3[3], void *stream, const char *who) {
+    NMFCHK(need_dev(x, who)); NMFCHK(need_dev(y, who));
+    if (!same_shape(x, y)) return shape_err(who);
+    const size_t n = (size_t)x.dim[0] * x.dim[1];
+    const int groups = reduce_num_groups(n);
+    double *part = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc((void **)&part, sizeof(double) * 3 * (size_t)groups));
+    HIPCHK(hipMalloc((void **)&out, sizeof(double) * 3));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_kl_reduce(x.mat_d, y.mat_d, n, part, st);
+    if (e == hipSuccess) e = launch_check_final(part, groups, out, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out3, out, sizeof(double) * 3, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(part); (void)hipFree(out);
+    HIPCHK(e);
+    return NMF_OK;
+}
+extern "C" int nmf_kl_divergence(matrix x, matrix y, double *kl, void *stream) {
+    if (!kl) return NMF_ERR_ARG;
+    double o[3];
+    NMFCHK(reduce3(x, y, o, stream, "kl_divergence"));
+    *kl = o[0];
+    return NMF_OK;
+}
+extern "C" int nmf_diff_norm(matrix x, matrix y, double *sum_abs_diff, double *sum_abs_x, void *stream) {
+    double o[3];
+    NMFCHK(reduce3(x, y, o, stream, "diff_norm"));
+    if (sum_abs_diff) *sum_abs_diff = o[1];
+    if (sum_abs_x) *sum_abs_x = o[2];
+    return NMF_OK;
+}
+
+// ------------------------------------------------------------------------------ matrix helpers
+extern "C" int nmf_create_matrix(matrix *A, int rows, int cols, float value) {
+    if (!A || rows <= 0 || cols <= 0) return NMF_ERR_ARG;
+    const size_t n = (size_t)rows * cols;
+    A->mat = (float *)malloc(n * sizeof(float));
+    if (!A->mat) return NMF_ERR_NOMEM;
+    for (size_t i = 0; i < n; ++i) A->mat[i] = value;
+    A->mat_d = nullptr;
+    A->dim[0] = rows; A->dim[1] = cols;
+    return NMF_OK;
+}
+extern "C" int nmf_matrix_free_device(matrix *A) {
+    if (!A) return NMF_ERR_ARG;
+    if (A->mat_d) { HIPCHK(hipFree(A->mat_d)); A->mat_d = nullptr; }
+    return NMF_OK;
+}
+extern "C" void nmf_destroy_matrix(matrix *A) {
+    if (!A) return;
+    if (A->mat) free(A->mat);
+    A->mat = nullptr;
+    if (A->mat_d) (void)hipFree(A->mat_d);
+    A->mat_d = nullptr;
+    A->dim[0] = A->dim[1] = 0;
+}
+extern "C" int nmf_matrix_to_device(matrix *A) {
+    if (!A || !A->mat || A->dim[0] <= 0 || A->dim[1] <= 0) return NMF_ERR_ARG;
+    const size_t bytes = (size_t)A->dim[0] * A->dim[1] * sizeof(float);   // 64-bit sizes (cf. uint32 overflow, cuda/matrix.cu:61)
+    if (!A->mat_d) HIPCHK(hipMalloc((void **)&A->mat_d, bytes));
+    HIPCHK(hipMemcpy(A->mat_d, A->mat, bytes, hipMemcpyHostToDevice));
+    return NMF_OK;
+}
+extern "C" int nmf_matrix_from_device(matrix *A) {
+    if (!A || !A->mat || !A->mat_d) return NMF_ERR_ARG;
+    const size_t bytes = (size_t)A->dim[0] * A->dim[1] * sizeof(float);
+    HIPCHK(hipMemcpy(A->mat, A->mat_d, bytes, hipMemcpyDeviceToHost));
+    return NMF_OK;
+}
+
+// cuda/nmf.cu:188-218 (the host copy stays raw; the EPS clamp is applied to device copies on upload)
+extern "C" int nmf_read_matrix(matrix *A, const char *file) {
+    if (!A || !file) return NMF_ERR_ARG;
+    FILE *fp = fopen(file, "rb");
+    if (!fp) { set_err("read_matrix: cannot open %s", file); return NMF_ERR_IO; }
+    uint32_t rc[2];
+    if (fread(rc, sizeof(uint32_t), 2, fp) != 2) { fclose(fp); set_err("read_matrix: %s: short header", file); return NMF_ERR_IO; }
+    if (rc[0] == 0 || rc[1] == 0 || rc[0] > 0x7fffffffu || rc[1] > 0x7fffffffu) { fclose(fp); set_err("read_matrix: %s: bad dims", file); return NMF_ERR_IO; }
+    const size_t n = (size_t)rc[0] * rc[1];
+    float *buf = (float *)malloc(n * sizeof(float));
+    if (!buf) { fclose(fp); return NMF_ERR_NOMEM; }
+    if (fread(buf, sizeof(float), n, fp) != n) { free(buf); fclose(fp); set_err("read_matrix: %s: short data", file); return NMF_ERR_IO; }
+    fclose(fp);
+    A->mat = buf; A->mat_d = nullptr; A->dim[0] = (int)rc[0]; A->dim[1] = (int)rc[1];
+    return NMF_OK;
+}
+// cuda/nmf.cu:220-259
+extern "C" int nmf_write_matrix(matrix A, const char *file) {
+    if (!A.mat || !file || A.dim[0] <= 0 || A.dim[1] <= 0) return NMF_ERR_ARG;
+    FILE *fp = fopen(file, "wb");
+    if (!fp) { set_err("write_matrix: cannot open %s", file); return NMF_ERR_IO; }
+    uint32_t rc[2] = {(uint32_t)A.dim[0], (uint32_t)A.dim[1]};
+    const size_t n = (size_t)A.dim[0] * A.dim[1];
+    const bool ok = fwrite(rc, sizeof(uint32_t), 2, fp) == 2 && fwrite(A.mat, sizeof(float), n, fp) == n;
+    fclose(fp);
+    if (!ok) { set_err("write_matrix: %s: short write", file); return NMF_ERR_IO; }
+    return NMF_OK;
+}

@@ -1,0 +1,80 @@
+// nmf_kernels.h -- internal launch API of the gfx950 kernels (not part of the C ABI).
+// All launchers enqueue on `stream`, never synchronise, never allocate, and return the
+// hipError_t of the launch (hipGetLastError), so they are safe inside hipGraph capture.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nmf {
+
+constexpr float kEps = (float)(2.2204E-16);   // cuda/matrix.cu:10
+constexpr int kPad = 32;                      // device buffers are padded to multiples of 32 (cf. PAD_MULT, cuda/matrix.cuh:7)
+constexpr int kMaxFusedKT = 8;                // fused path: K_padded <= 256
+
+inline int pad32(int v) { return (v + 31) & ~31; }
+
+// ---------------------------------------------------------------- fused half-steps
+// One half-step of update_div on zero-padded device buffers (all dims multiples of 32).
+//   H-step (wstep=false): streamed factor V = W (Mp x Kp), owned factor U = H (Kp x Np).
+//   W-step (wstep=true) : streamed factor V = H,           owned factor U = W.
+// Each wave owns 32 columns (H-step) / rows (W-step) of U and streams V in 32-wide chunks
+// of the reduction dimension; nsplit > 1 splits that dimension over workgroups and writes
+// raw partial products to `partials` (nsplit slabs in U's layout) instead of updating U.
+struct FusedArgs {
+    const float *W; const float *H; const float *X;   // inputs (W: Mp x Kp, H: Kp x Np, X: Mp x Np)
+    float *U_out;             // nsplit == 1: the factor updated in place (H or W)
+    float *partials;          // nsplit  > 1: nsplit slabs of Kp*Np (H-step) or Mp*Kp (W-step) floats
+    const float *norm;        // Kp clamped normalisers (colsum(W) for the H-step, rowsum(H) for the W-step); nsplit == 1 only
+    int Mp, Np, Kp;
+    int nsplit;
+    int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
+};
+hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
+// U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
+hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
+                                 int Mp, int Np, int Kp, bool wstep, hipStream_t stream);
+// psum = sum_s partials[s]   (sharded W-step: operand of the all-reduce)
+hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream);
+// W[m,k] *= psum[m,k] / max(hsum[k], EPS)
+hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp, int Kp, hipStream_t stream);
+
+// KL(X || max(W*H,EPS)), sum|X-WH|, sum|X| over the valid (non-padded, X > 0) entries:
+// per-workgroup partial triples into `part` (3 doubles per workgroup), then launch_check_final.
+int        check_num_groups(int Np);
+hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,
+                        double *part, hipStream_t stream);
+hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
+
+// ---------------------------------------------------------------- normalisers
+// out[k] = max(sum_i A[i + k*ld], EPS), one workgroup per column (sum_cols + set_epsilon, cuda/nmf.cu:134-135)
+hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream);
+// row sums in two deterministic levels: part[b][k] then out[k] = max(sum_b part[b][k], EPS) (cuda/nmf.cu:164-165)
+int        row_sum_blocks(int cols);
+hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp,
+                           hipStream_t stream);
+
+// ---------------------------------------------------------------- unfused operators
+enum GemmKind { GEMM_NN = 0, GEMM_TN = 1, GEMM_NT = 2 };
+// C(m x n, ldc) = op(A) * op(B) with reduction length k; fp32 MFMA, arbitrary sizes.
+hipError_t launch_gemm(GemmKind kind, int m, int n, int k, const float *A, long lda, const float *B, long ldb,
+                       float *C, long ldc, hipStream_t stream);
+hipError_t launch_set_epsilon(float *a, size_t n, hipStream_t stream);
+hipError_t launch_vec_div(const float *a, const float *b, float *c, size_t n, hipStream_t stream);
+hipError_t launch_vec_mul(const float *a, const float *b, float *c, size_t n, hipStream_t stream);
+// c[i + j*ld] = a[i + j*ld] / b[i]   (col_div, cuda/matrix.cu:244-250)
+hipError_t launch_col_div(const float *a, const float *b, float *c, int rows, int cols, long ld, hipStream_t stream);
+// c[i + j*ld] = a[i + j*ld] / b[j]   (row_div, cuda/matrix.cu:220-224)
+hipError_t launch_row_div(const float *a, const float *b, float *c, int rows, int cols, long ld, hipStream_t stream);
+// generic KL / diff reductions over two flat arrays (reduce1d_div / reduce1d_diff): 3 doubles per group
+int        reduce_num_groups(size_t n);
+hipError_t launch_kl_reduce(const float *x, const float *y, size_t n, double *part, hipStream_t stream);
+
+// ---------------------------------------------------------------- padding helpers
+// dst (rows_p x cols_p, ld = rows_p) <- src (rows x cols, ld = rows), zero padding, optional EPS clamp of the
+// valid region (read_matrix's set_epsilon, cuda/nmf.cu:211)
+hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp,
+                           hipStream_t stream);
+hipError_t launch_unpad_copy(float *dst, int rows, int cols, const float *src, int rows_p, hipStream_t stream);
+
+}  // namespace nmf

@@ -1,0 +1,684 @@
+// nmf_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the update_div hot path.
+//
+// Written for wave64 + the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.  Operand / result maps
+// used everywhere below (lane l: c = l & 31, h = l >> 5):
+//     A operand : one float = A[row c][k = h]
+//     B operand : one float = B[k = h][col c]
+//     C/D tile  : reg r (0..15) = D[row rho(r) + 4h][col c],  rho(r) = (r & 3) + 8 (r >> 2)
+// Consequence exploited by the fused kernels: register r of a finished 32x32 tile IS a valid B
+// operand of a following MFMA whose two k indices are rows rho(r) and rho(r)+4 of that tile, so
+// the quotient Z = X ./ max(W*H, EPS) feeds the second GEMM of a half-step straight from the
+// accumulator registers and never exists in LDS or HBM.
+//
+// Reference semantics restated (not translated): cuda/nmf.cu:118-176 (half-steps),
+// cuda/matrix.cu:97-250 (operators), cuda/matrix.cu:505-735 (reductions).
+#include "nmf_kernels.h"
+
+namespace nmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NMF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ constexpr int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// set_epsilon semantics (cuda/matrix.cu:185-186): a clamp, NaN passes through.
+__device__ __forceinline__ float clamp_eps(float v) { return (v < kEps) ? kEps : v; }
+
+// 64-lane sum, result valid in lane 0
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// =====================================================================================
+// Fused half-step
+// =====================================================================================
+// LDS image of one streamed chunk: Vl[k][p], p = 0..31 within the chunk, row stride 33 floats.
+//   product-1 A operand  Vl[(2s+h)*33 + c]          : 32 consecutive banks            -> conflict-free
+//   product-2 A operand  Vl[(32t+c)*33 + rho(r)+4h] : stride 33 (odd) across 32 lanes -> conflict-free
+constexpr int kLdv = 33;
+
+template <int KT, bool WSTEP>
+__device__ __forceinline__ void stage_load(f32x4 (&st)[KT], const float *__restrict__ V, long ldv, int p0, int tid) {
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        const int f = tid + q * 256;
+        if (!WSTEP) {   // V = W (p contiguous): K rows of 32 floats
+            const int k = f >> 3, i4 = f & 7;
+            st[q] = *reinterpret_cast<const f32x4 *>(V + (size_t)(p0 + 4 * i4) + (size_t)k * ldv);
+        } else {        // V = H (k contiguous): 32 columns of K floats
+            const int k4 = f % (KT * 8), i = f / (KT * 8);
+            st[q] = *reinterpret_cast<const f32x4 *>(V + (size_t)(4 * k4) + (size_t)(p0 + i) * ldv);
+        }
+    }
+}
+
+template <int KT, bool WSTEP>
+__device__ __forceinline__ void stage_store(const f32x4 (&st)[KT], float *__restrict__ vl, int tid) {
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        const int f = tid + q * 256;
+        if (!WSTEP) {
+            const int k = f >> 3, i4 = f & 7;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vl[k * kLdv + 4 * i4 + c] = st[q][c];
+        } else {
+            const int k4 = f % (KT * 8), i = f / (KT * 8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vl[(4 * k4 + c) * kLdv + i] = st[q][c];
+        }
+    }
+}
+
+// X tile of chunk p0 in the accumulator layout: xr[r] = X(p0 + rho(r) + 4h, q0 + c)
+template <bool WSTEP>
+__device__ __forceinline__ void load_x(float (&xr)[16], const float *__restrict__ X, long ldx, int p0, int q0, int c, int h) {
+    if (!WSTEP) {   // X(p,q) = X[p + q*ld]: 4 consecutive p per lane per group
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(X + (size_t)(p0 + 8 * g + 4 * h) + (size_t)(q0 + c) * ldx);
+            xr[4 * g + 0] = v[0]; xr[4 * g + 1] = v[1]; xr[4 * g + 2] = v[2]; xr[4 * g + 3] = v[3];
+        }
+    } else {        // X(p,q) = X[q + p*ld]: lanes run along q, coalesced
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = X[(size_t)(q0 + c) + (size_t)(p0 + rho(r) + 4 * h) * ldx];
+    }
+}
+
+// B operands of product 1, resident for the whole kernel: ub[s] = U(k = 2s + h, q0 + c)
+template <int KT, bool WSTEP>
+__device__ __forceinline__ void load_u(float (&ub)[KT * 16], const float *__restrict__ U, long ldu, int q0, int c, int h) {
+#pragma unroll
+    for (int s = 0; s < KT * 16; ++s) {
+        const int k = 2 * s + h;
+        ub[s] = WSTEP ? U[(size_t)(q0 + c) + (size_t)k * ldu] : U[(size_t)k + (size_t)(q0 + c) * ldu];
+    }
+}
+
+template <int KT>
+__device__ __forceinline__ f32x16 product1(const float (&ub)[KT * 16], const float *__restrict__ vb, int c, int h) {
+    f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < KT * 16; ++ss) s = NMF_MFMA(vb[(2 * ss + h) * kLdv + c], ub[ss], s);
+    return s;
+}
+
+template <int KT, bool WSTEP, bool PARTIAL>
+__global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = KT * 32;
+    constexpr int VBUF = KP * kLdv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int P = WSTEP ? a.Np : a.Mp;   // streamed / reduced dimension
+    const int Q = WSTEP ? a.Mp : a.Np;   // owned dimension
+    const int nsplit = a.nsplit;
+    const int split = blockIdx.x % nsplit;   // workgroups of one split share the V stream (same XCD under round-robin)
+    const int qblk = blockIdx.x / nsplit;
+    int q0 = (qblk * 4 + wave) * 32;
+    const bool active = q0 < Q;
+    if (!active) q0 = Q - 32;                // tail wave: recompute a valid slice, store nothing
+    const float *__restrict__ V = WSTEP ? a.H : a.W;
+    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
+    const int nchunks = P / 32;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * cps;
+    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
+
+    float ub[KT * 16];
+    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (c_begin < c_end) {
+        f32x4 st[KT];
+        float xr[16];
+        stage_load<KT, WSTEP>(st, V, ldv, c_begin * 32, tid);
+        load_x<WSTEP>(xr, a.X, ldx, c_begin * 32, q0, c, h);
+        stage_store<KT, WSTEP>(st, smem, tid);
+        __syncthreads();
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int par = (ch - c_begin) & 1;
+            const float *__restrict__ vb = smem + par * VBUF;
+            float *__restrict__ vn = smem + (par ^ 1) * VBUF;
+            const bool more = ch + 1 < c_end;
+            if (more) stage_load<KT, WSTEP>(st, V, ldv, (ch + 1) * 32, tid);
+
+            // product 1: S(32 p x 32 q) = V_chunk * U_slice, reduction over K (one dependent MFMA chain)
+            const f32x16 s = product1<KT>(ub, vb, c, h);
+
+            // quotient Z = X ./ max(S, EPS)  (set_epsilon + vec_div, cuda/nmf.cu:128-131)
+            float z[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = xr[r] / clamp_eps(s[r]);
+            if (more) load_x<WSTEP>(xr, a.X, ldx, (ch + 1) * 32, q0, c, h);
+
+            // product 2: Acc(K x 32 q) += V_chunk' * Z, reduction over the chunk's 32 p;
+            // z[r] is the B operand for the k-pair (rho(r), rho(r)+4).
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    acc[t] = NMF_MFMA(vb[(32 * t + c) * kLdv + rho(r) + 4 * h], z[r], acc[t]);
+            }
+            if (more) stage_store<KT, WSTEP>(st, vn, tid);
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+
+    // epilogue: lane holds Acc(k = 32t + rho(r) + 4h, q0 + c)
+    if (PARTIAL) {
+        const size_t slab = WSTEP ? (size_t)a.Mp * a.Kp : (size_t)a.Kp * a.Np;
+        float *__restrict__ out = a.partials + (size_t)split * slab;
+        if (!WSTEP) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(out + (size_t)(32 * t + 8 * g + 4 * h) + (size_t)(q0 + c) * ldu) = v;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[(size_t)(q0 + c) + (size_t)(32 * t + rho(r) + 4 * h) * ldu] = acc[t][r];
+        }
+    } else {
+        float *__restrict__ Uo = a.U_out;
+        const float *__restrict__ nrm = a.norm;
+        if (!WSTEP) {   // H[k,n] = H[k,n] * (WtZ[k,n] / sumW[k])   (col_div then vec_mul, cuda/nmf.cu:142-145)
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k = 32 * t + 8 * g + 4 * h;
+                    float *p = Uo + (size_t)k + (size_t)(q0 + c) * ldu;
+                    f32x4 u = *reinterpret_cast<const f32x4 *>(p);
+                    const f32x4 n4 = *reinterpret_cast<const f32x4 *>(nrm + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[e] = u[e] * (acc[t][4 * g + e] / n4[e]);
+                    *reinterpret_cast<f32x4 *>(p) = u;
+                }
+        } else {        // W[m,k] = W[m,k] * (ZHt[m,k] / sumH[k])   (row_div then vec_mul, cuda/nmf.cu:172-175)
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = 32 * t + rho(r) + 4 * h;
+                    float *p = Uo + (size_t)(q0 + c) + (size_t)k * ldu;
+                    *p = *p * (acc[t][r] / nrm[k]);
+                }
+        }
+    }
+}
+
+template <int KT>
+static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t stream) {
+    const int Q = wstep ? a.Mp : a.Np;
+    const int nqblk = (Q + 127) / 128;
+    const dim3 grid((unsigned)(nqblk * a.nsplit)), block(256);
+    const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
+    const bool partial = a.partial != 0;
+#define NMF_LAUNCH_FUSED(W_, P_)                                                                          \
+    do {                                                                                                  \
+        static bool attr_done = false;                                                                    \
+        if (!attr_done) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void *)fused_step_kernel<KT, W_, P_>,               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            if (e != hipSuccess) return e;                                                                \
+            attr_done = true;                                                                             \
+        }                                                                                                 \
+        hipLaunchKernelGGL((fused_step_kernel<KT, W_, P_>), grid, block, lds, stream, a);                 \
+    } while (0)
+    if (!wstep && !partial) NMF_LAUNCH_FUSED(false, false);
+    else if (!wstep && partial) NMF_LAUNCH_FUSED(false, true);
+    else if (wstep && !partial) NMF_LAUNCH_FUSED(true, false);
+    else NMF_LAUNCH_FUSED(true, true);
+#undef NMF_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
+    if ((a.Mp | a.Np | a.Kp) & 31) return hipErrorInvalidValue;
+    if (a.nsplit < 1 || (a.nsplit > 1 && !a.partial)) return hipErrorInvalidValue;
+    switch (a.Kp / 32) {
+        case 1: return launch_fused_kt<1>(a, wstep, stream);
+        case 2: return launch_fused_kt<2>(a, wstep, stream);
+        case 4: return launch_fused_kt<4>(a, wstep, stream);
+        case 8: return launch_fused_kt<8>(a, wstep, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------ partial reduce + apply
+template <bool WSTEP>
+__global__ __launch_bounds__(256) void apply_partials_kernel(float *__restrict__ U, const float *__restrict__ P, int nsplit,
+                                                             const float *__restrict__ nrm, size_t count, int Mp, int Kp) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float s = P[i];
+        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
+        const int k = WSTEP ? (int)(i / (size_t)Mp) : (int)(i % (size_t)Kp);
+        U[i] = U[i] * (s / nrm[k]);
+    }
+}
+
+static inline unsigned ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm, int Mp, int Np, int Kp,
+                                 bool wstep, hipStream_t stream) {
+    const size_t count = wstep ? (size_t)Mp * Kp : (size_t)Kp * Np;
+    if (wstep) hipLaunchKernelGGL(apply_partials_kernel<true>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, count, Mp, Kp);
+    else       hipLaunchKernelGGL(apply_partials_kernel<false>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, count, Mp, Kp);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ out, const float *__restrict__ P, int nsplit, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float s = P[i];
+        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
+        out[i] = s;
+    }
+}
+hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, psum, partials, nsplit, count);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void apply_w_kernel(float *__restrict__ W, const float *__restrict__ psum, const float *__restrict__ hsum,
+                                                      size_t count, int Mp) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i / (size_t)Mp);
+        W[i] = W[i] * (psum[i] / clamp_eps(hsum[k]));
+    }
+}
+hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp, int Kp, hipStream_t stream) {
+    const size_t count = (size_t)Mp * Kp;
+    hipLaunchKernelGGL(apply_w_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, W, psum, hsum, count, Mp);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Convergence check: KL(X || WH), sum|X - WH|, sum|X|  (reduce1d_div / reduce1d_diff,
+// cuda/matrix.cu:505-640) fused behind product 1 so W*H is never materialised.
+// =====================================================================================
+__device__ __forceinline__ void block_reduce3(double v0, double v1, double v2, double *out3, int tid) {
+    __shared__ double red[3][4];
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; red[2][tid >> 6] = v2; }
+    __syncthreads();
+    if (tid == 0) {
+        out3[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out3[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        out3[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256, 1) void check_kernel(const float *__restrict__ W, const float *__restrict__ H, const float *__restrict__ X,
+                                                       int Mp, int Np, int Kp, double *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VBUF = KT * 32 * kLdv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < Np;
+    if (!active) q0 = Np - 32;
+    float ub[KT * 16];
+    load_u<KT, false>(ub, H, Kp, q0, c, h);
+    double kl = 0.0, dabs = 0.0, xabs = 0.0;
+    const int nchunks = Mp / 32;
+    f32x4 st[KT];
+    float xr[16];
+    stage_load<KT, false>(st, W, Mp, 0, tid);
+    load_x<false>(xr, X, Mp, 0, q0, c, h);
+    stage_store<KT, false>(st, smem, tid);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float *__restrict__ vb = smem + (ch & 1) * VBUF;
+        float *__restrict__ vn = smem + ((ch & 1) ^ 1) * VBUF;
+        const bool more = ch + 1 < nchunks;
+        if (more) stage_load<KT, false>(st, W, Mp, (ch + 1) * 32, tid);
+        const f32x16 s = product1<KT>(ub, vb, c, h);
+        float fkl = 0.f, fd = 0.f, fx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = xr[r], y = clamp_eps(s[r]);
+            if (x > 0.f) {   // padding is exactly 0; real inputs are >= EPS (cuda/nmf.cu:211)
+                fkl += x * (logf(x) - logf(y)) - x + y;   // cuda/matrix.cu:592
+                fd += fabsf(x - y);                       // cuda/matrix.cu:517
+                fx += fabsf(x);                           // cuda/matrix.cu:518
+            }
+        }
+        kl += (double)fkl; dabs += (double)fd; xabs += (double)fx;
+        if (more) load_x<false>(xr, X, Mp, (ch + 1) * 32, q0, c, h);
+        if (more) stage_store<KT, false>(st, vn, tid);
+        __syncthreads();
+    }
+    if (!active) { kl = 0.0; dabs = 0.0; xabs = 0.0; }
+    block_reduce3(kl, dabs, xabs, part + 3 * (size_t)blockIdx.x, tid);
+}
+
+int check_num_groups(int Np) { return (Np + 127) / 128; }
+
+template <int KT>
+static hipError_t launch_check_kt(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+    const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)check_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((check_kernel<KT>), dim3(check_num_groups(Np)), dim3(256), lds, stream, W, H, X, Mp, Np, Kp, part);
+    return hipGetLastError();
+}
+
+hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+    if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
+    switch (Kp / 32) {
+        case 1: return launch_check_kt<1>(W, H, X, Mp, Np, Kp, part, stream);
+        case 2: return launch_check_kt<2>(W, H, X, Mp, Np, Kp, part, stream);
+        case 4: return launch_check_kt<4>(W, H, X, Mp, Np, Kp, part, stream);
+        case 8: return launch_check_kt<8>(W, H, X, Mp, Np, Kp, part, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// out3[v] = sum_g part[3g + v], fixed order (one workgroup)
+__global__ __launch_bounds__(256) void check_final_kernel(const double *__restrict__ part, int ngroups, double *__restrict__ out3) {
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (int g = threadIdx.x; g < ngroups; g += 256) { v0 += part[3 * (size_t)g]; v1 += part[3 * (size_t)g + 1]; v2 += part[3 * (size_t)g + 2]; }
+    block_reduce3(v0, v1, v2, out3, threadIdx.x);
+}
+hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream) {
+    hipLaunchKernelGGL(check_final_kernel, dim3(1), dim3(256), 0, stream, part, ngroups, out3);
+    return hipGetLastError();
+}
+
+// generic flat version for the unfused path: x = X, y = WH (already clamped by the caller)
+__global__ __launch_bounds__(256) void kl_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, size_t n, double *__restrict__ part) {
+    double kl = 0.0, dabs = 0.0, xabs = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float xv = x[i], yv = y[i];
+        if (xv > 0.f) {
+            kl += (double)(xv * (logf(xv) - logf(yv)) - xv + yv);
+            dabs += (double)fabsf(xv - yv);
+            xabs += (double)fabsf(xv);
+        }
+    }
+    block_reduce3(kl, dabs, xabs, part + 3 * (size_t)blockIdx.x, threadIdx.x);
+}
+int reduce_num_groups(size_t n) {
+    size_t g = (n + 256 * 16 - 1) / (256 * 16);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+hipError_t launch_kl_reduce(const float *x, const float *y, size_t n, double *part, hipStream_t stream) {
+    hipLaunchKernelGGL(kl_reduce_kernel, dim3(reduce_num_groups(n)), dim3(256), 0, stream, x, y, n, part);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Normalisers (sum_cols / sum_rows + set_epsilon, cuda/nmf.cu:134-135, 164-165)
+// wave64 shuffle tree + LDS across the 4 waves; fixed summation order -> reproducible.
+// =====================================================================================
+__global__ __launch_bounds__(256) void col_sums_kernel(const float *__restrict__ A, int rows, long ld, float *__restrict__ out, int clamp) {
+    __shared__ float red[4];
+    const float *__restrict__ a = A + (size_t)blockIdx.x * ld;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) s += a[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        out[blockIdx.x] = clamp ? clamp_eps(tot) : tot;
+    }
+}
+hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream) {
+    hipLaunchKernelGGL(col_sums_kernel, dim3(cols), dim3(256), 0, stream, A, rows, ld, out, clamp ? 1 : 0);
+    return hipGetLastError();
+}
+
+constexpr int kRowSumCols = 256;   // columns per workgroup in level 1
+int row_sum_blocks(int cols) { return (cols + kRowSumCols - 1) / kRowSumCols; }
+
+// level 1: part[b*rows + k] = sum over this block's columns of A[k + col*ld]
+__global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restrict__ A, int rows, int cols, long ld, float *__restrict__ part) {
+    __shared__ float red[256];
+    const int c0 = blockIdx.x * kRowSumCols;
+    const int c1 = (c0 + kRowSumCols < cols) ? c0 + kRowSumCols : cols;
+    float *__restrict__ outp = part + (size_t)blockIdx.x * rows;
+    if (rows >= 256) {
+        for (int k = threadIdx.x; k < rows; k += 256) {
+            float s = 0.f;
+            for (int col = c0; col < c1; ++col) s += A[(size_t)k + (size_t)col * ld];
+            outp[k] = s;
+        }
+    } else {
+        const int nsub = 256 / rows;             // column phases handled in parallel
+        const int k = threadIdx.x % rows, sub = threadIdx.x / rows;
+        float s = 0.f;
+        if (sub < nsub)
+            for (int col = c0 + sub; col < c1; col += nsub) s += A[(size_t)k + (size_t)col * ld];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < rows) {
+            float tot = red[threadIdx.x];
+            for (int q = 1; q < nsub; ++q) tot += red[threadIdx.x + q * rows];
+            outp[threadIdx.x] = tot;
+        }
+    }
+}
+// level 2: out[k] = sum_b part[b*rows + k]
+__global__ __launch_bounds__(256) void row_sums_l2_kernel(const float *__restrict__ part, int rows, int nblk, float *__restrict__ out, int clamp) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= rows) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * rows + k];
+    out[k] = clamp ? clamp_eps(s) : s;
+}
+hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp, hipStream_t stream) {
+    const int nblk = row_sum_blocks(cols);
+    hipLaunchKernelGGL(row_sums_l1_kernel, dim3(nblk), dim3(256), 0, stream, A, rows, cols, ld, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(row_sums_l2_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, part, rows, nblk, out, clamp ? 1 : 0);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Unfused operators (one per reference operator; also the K > 256 fallback)
+// =====================================================================================
+// Generic fp32 MFMA GEMM, 128 x 128 x 16 tiles, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA
+// tiles.  The MFMA is issued "transposed" (B-side value as the A operand) so that the lane index
+// of the result runs along the rows of C: stores are 128-byte coalesced in column-major C.
+//   A(i,l) = A[i*sai + l*sal],  B(l,j) = B[l*sbl + j*sbj],  C(i,j) = C[i + j*ldc]
+constexpr int kGemmLd = 129;
+template <bool A_LCONTIG, bool B_LCONTIG>
+__global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, const float *__restrict__ A, long sai, long sal,
+                                                   const float *__restrict__ B, long sbl, long sbj, float *__restrict__ C, long ldc) {
+    __shared__ float As[16 * kGemmLd];
+    __shared__ float Bs[16 * kGemmLd];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i_base = blockIdx.x * 128, j_base = blockIdx.y * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    float ra[8], rb[8];
+    auto fetch = [&](int l0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * 256;
+            const int la = A_LCONTIG ? (e & 15) : (e >> 7), ia = A_LCONTIG ? (e >> 4) : (e & 127);
+            const int gi = i_base + ia, gl = l0 + la;
+            ra[q] = (gi < m && gl < k) ? A[(size_t)gi * sai + (size_t)gl * sal] : 0.f;
+            const int lb = B_LCONTIG ? (e & 15) : (e >> 7), jb = B_LCONTIG ? (e >> 4) : (e & 127);
+            const int gj = j_base + jb, gl2 = l0 + lb;
+            rb[q] = (gj < n && gl2 < k) ? B[(size_t)gl2 * sbl + (size_t)gj * sbj] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * 256;
+            const int la = A_LCONTIG ? (e & 15) : (e >> 7), ia = A_LCONTIG ? (e >> 4) : (e & 127);
+            As[la * kGemmLd + ia] = ra[q];
+            const int lb = B_LCONTIG ? (e & 15) : (e >> 7), jb = B_LCONTIG ? (e >> 4) : (e & 127);
+            Bs[lb * kGemmLd + jb] = rb[q];
+        }
+    };
+    fetch(0);
+    for (int l0 = 0; l0 < k; l0 += 16) {
+        commit();
+        __syncthreads();
+        if (l0 + 16 < k) fetch(l0 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = As[(2 * kk + h) * kGemmLd + wm * 64 + t * 32 + c];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bv[u] = Bs[(2 * kk + h) * kGemmLd + wn * 64 + u * 32 + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = NMF_MFMA(bv[u], av[t], acc[t][u]);   // D[j-off][i-off]: lane runs along i
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = i_base + wm * 64 + t * 32 + c;
+                const int gj = j_base + wn * 64 + u * 32 + rho(r) + 4 * h;
+                if (gi < m && gj < n) C[(size_t)gi + (size_t)gj * ldc] = acc[t][u][r];
+            }
+}
+
+hipError_t launch_gemm(GemmKind kind, int m, int n, int k, const float *A, long lda, const float *B, long ldb, float *C, long ldc,
+                       hipStream_t stream) {
+    if (m <= 0 || n <= 0 || k <= 0) return hipErrorInvalidValue;
+    const dim3 grid((m + 127) / 128, (n + 127) / 128), block(256);
+    switch (kind) {
+        case GEMM_NN:   // A(i,l) = A[i + l*lda]; B(l,j) = B[l + j*ldb]
+            hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, 1L, ldb, C, ldc);
+            break;
+        case GEMM_TN:   // A stored (k x m): A(i,l) = A[l + i*lda]
+            hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, m, n, k, A, lda, 1L, B, 1L, ldb, C, ldc);
+            break;
+        case GEMM_NT:   // B stored (n x k): B(l,j) = B[j + l*ldb]
+            hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, ldb, 1L, C, ldc);
+            break;
+    }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void set_epsilon_kernel(float *__restrict__ a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = a[i];
+        if (v < kEps) a[i] = kEps;
+    }
+}
+hipError_t launch_set_epsilon(float *a, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(set_epsilon_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void vec_div_kernel(const float *a, const float *b, float *c, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c[i] = a[i] / b[i];
+}
+hipError_t launch_vec_div(const float *a, const float *b, float *c, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vec_div_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, b, c, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void vec_mul_kernel(const float *a, const float *b, float *c, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c[i] = a[i] * b[i];
+}
+hipError_t launch_vec_mul(const float *a, const float *b, float *c, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vec_mul_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, a, b, c, n);
+    return hipGetLastError();
+}
+
+// c[i + j*ld] = a[i + j*ld] / b[BY_ROW ? i : j]
+template <bool BY_ROW>
+__global__ __launch_bounds__(256) void bcast_div_kernel(const float *a, const float *b, float *c, int rows, int cols, long ld) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % (size_t)rows), j = (int)(e / (size_t)rows);
+        const size_t ix = (size_t)i + (size_t)j * ld;
+        c[ix] = a[ix] / b[BY_ROW ? i : j];
+    }
+}
+hipError_t launch_col_div(const float *a, const float *b, float *c, int rows, int cols, long ld, hipStream_t stream) {
+    hipLaunchKernelGGL(bcast_div_kernel<true>, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, a, b, c, rows, cols, ld);
+    return hipGetLastError();
+}
+hipError_t launch_row_div(const float *a, const float *b, float *c, int rows, int cols, long ld, hipStream_t stream) {
+    hipLaunchKernelGGL(bcast_div_kernel<false>, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, a, b, c, rows, cols, ld);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Padding
+// =====================================================================================
+__global__ __launch_bounds__(256) void pad_copy_kernel(float *__restrict__ dst, int rows_p, int cols_p, const float *__restrict__ src, int rows, int cols,
+                                                       int clamp) {
+    const size_t n = (size_t)rows_p * cols_p;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % (size_t)rows_p), j = (int)(e / (size_t)rows_p);
+        float v = 0.f;
+        if (i < rows && j < cols) {
+            v = src[(size_t)i + (size_t)j * rows];
+            if (clamp) v = clamp_eps(v);
+        }
+        dst[e] = v;
+    }
+}
+hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(ew_grid((size_t)rows_p * cols_p)), dim3(256), 0, stream, dst, rows_p, cols_p, src, rows, cols, clamp ? 1 : 0);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void unpad_copy_kernel(float *__restrict__ dst, int rows, int cols, const float *__restrict__ src, int rows_p) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % (size_t)rows), j = (int)(e / (size_t)rows);
+        dst[e] = src[(size_t)i + (size_t)j * rows_p];
+    }
+}
+hipError_t launch_unpad_copy(float *dst, int rows, int cols, const float *src, int rows_p, hipStream_t stream) {
+    hipLaunchKernelGGL(unpad_copy_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, stream, dst, rows, cols, src, rows_p);
+    return hipGetLastError();
+}
+
+}  // namespace nmf

@@ -1,0 +1,50 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import nmf_gpu_amd as ng
+        return ng.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not skip: only auto-skip when the
+    # user did not ask for gpu tests explicitly.
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def ng():
+    import nmf_gpu_amd as m
+    m.lib()
+    return m
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,244 @@
+"""GPU parity of the update_div loop (8d parity gates) against
+the CPU oracle in `spec` mode, through the C ABI.
+
+Tolerance (north_star): rel-Frobenius <= 1e-4 on W, on H and on W*H after 200 iterations,
+fp32 on both sides (element-wise comparison is meaningless, entries span
+1e-45 .. 1e2 and the dynamics amplify summation-order differences)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _cmp(oracle, W, H, Wr, Hr, tol=TOL, wh=True):
+    eW, eH = oracle.relF(W, Wr), oracle.relF(H, Hr)
+    eWH = oracle.relF(W.astype(np.float64) @ H.astype(np.float64), Wr.astype(np.float64) @ Hr.astype(np.float64)) if wh else 0.0
+    assert eW < tol and eH < tol and eWH < tol, (eW, eH, eWH)
+    return eW, eH, eWH
+
+
+@pytest.mark.parametrize("path", ["fused", "unfused"])
+@pytest.mark.parametrize("M,N,K", [(64, 96, 32), (100, 70, 17), (257, 130, 64), (33, 1, 1), (1, 33, 5)])
+def test_half_steps_small(ng, oracle, path, M, N, K):
+    """one update_h then one update_w (cuda/nmf.cu:118-176), ragged and degenerate sizes"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=7)
+    s = ng.Solver(M, N, K, path=ng.PATH_FUSED if path == "fused" else ng.PATH_UNFUSED, use_graph=False)
+    s.upload(W, H, X)
+    s.update_h()
+    W1, H1 = s.download()
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert oracle.relF(H1, Hr) < 5e-6
+    assert np.array_equal(W1, oracle.clamp(W))
+    s.update_w()
+    W2, H2 = s.download()
+    Wr = oracle.update_w(oracle.clamp(W), Hr, oracle.clamp(X))
+    assert oracle.relF(W2, Wr) < 5e-6
+    assert np.array_equal(H2, H1)
+    s.close()
+
+
+@pytest.mark.parametrize("nsplit", [1, 2, 5])
+def test_split_reduction_equivalence(ng, oracle, nsplit):
+    """splitting the reduction dimension over workgroups only changes summation order"""
+    M, N, K = 320, 288, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=3)
+    s = ng.Solver(M, N, K, path=ng.PATH_FUSED, nsplit_h=nsplit, nsplit_w=nsplit, use_graph=False)
+    s.upload(W, H, X)
+    s.iterate(3)
+    Wg, Hg = s.download()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 3, 25)
+    _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5)
+    s.close()
+
+
+def test_cfg2_200_iters_fused(ng, oracle):
+    """BASELINE config 2: M=1024 N=4096 R=64, 200 iterations, vs CPU-fp32 spec oracle"""
+    M, N, K = 1024, 4096, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 200, None, 0)
+    Wr, Hr, it, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
+    assert it == 200
+    print("cfg2 fused relF(W,H,WH) =", _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr))
+
+
+def test_cfg2_unfused_matches(ng, oracle):
+    M, N, K = 1024, 4096, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=50, path=ng.PATH_UNFUSED)
+    assert r["path_used"] == ng.PATH_UNFUSED and r["iterations"] == 50
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 50, 25)
+    print("cfg2 unfused relF =", _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr))
+
+
+def test_gold_problem_spec_and_kl_trajectory(ng, oracle):
+    """The reference's own problem (matrix_export.py: 4096x350, K=128, seed 0), `spec` math.
+    KL known-answers from SURVEY 4.1 (fp32 numpy): it0 4.236641e7, it25 1.318188e5,
+    it50 1.213339e5, it100 1.059821e5, it200 9.668972e4."""
+    X, W, H = oracle.gen_problem(4096, 350, 128, seed=0)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=200, verbose=0, converge_thresh=1e-30)
+    kl = r["kl"]
+    assert r["iterations"] == 200 and len(kl) == 9
+    kat = {0: 4.236641e7, 1: 1.318188e5, 2: 1.213339e5, 4: 1.059821e5, 8: 9.668972e4}
+    for i, v in kat.items():
+        assert abs(kl[i] - v) / v < 2e-4, (i, kl[i], v)
+    assert all(kl[i + 1] < kl[i] for i in range(len(kl) - 1))
+    Wr, Hr, _, klr = oracle.update_div(W, H, X, 0.0, 200, 25)
+    print("gold/spec relF =", _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr))
+    assert np.allclose(kl, klr, rtol=2e-5)
+
+
+def test_gold_files_are_not_spec(ng, oracle):
+    """The reference's Wtest/Htest pin the bug-compatible `refcompat` model (oracle test),
+    not the intended math the GPU implements: document the distance so nobody compares
+    the GPU output with them by md5 (test_output.sh)."""
+    X, W, H = oracle.gen_problem(4096, 350, 128, seed=0)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 200, None, 0)
+    Wg = oracle.read_bin(os.path.join(GOLDEN, "Wtest.bin"))
+    assert oracle.relF(Wm.mat, Wg) > 0.1
+
+
+def test_convergence_stop_and_timers(ng, oracle):
+    M, N, K = 256, 512, 32
+    X, W, H = oracle.gen_problem(M, N, K, seed=5)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=2000, converge_thresh=1e-3, iter_check=25)
+    Wr, Hr, it, klr = oracle.update_div(W, H, X, 1e-3, 2000, 25)
+    assert r["iterations"] == it and it < 2000 and it % 25 == 0
+    assert np.allclose(r["kl"], klr, rtol=1e-4)
+    _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr, 2e-4)
+    # t[10] contract (README.md:53): eager + hipEvents
+    t = [0.0] * 10
+    ng.update_div(ng.Matrix(W), ng.Matrix(H), ng.Matrix(X), 0.0, 20, t, 0)
+    assert t[0] > 0 and t[2] > 0 and t[3] > 0 and t[0] >= t[2] + t[3]
+
+
+def test_graph_and_eager_identical(ng, oracle):
+    M, N, K = 512, 640, 128
+    X, W, H = oracle.gen_problem(M, N, K, seed=9)
+    outs = []
+    for g in (True, False):
+        s = ng.Solver(M, N, K, use_graph=g)
+        s.upload(W, H, X)
+        s.iterate(10)
+        outs.append(s.download())
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_rerun_deterministic(ng, oracle):
+    M, N, K = 384, 1000, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=11)
+    res = []
+    for _ in range(2):
+        Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+        ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 30, None, 0)
+        res.append((Wm.mat.copy(), Hm.mat.copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_zero_inputs_are_clamped(ng, oracle):
+    """read_matrix clamps every input to EPS (cuda/nmf.cu:211): zeros in X, W, H must not
+    produce NaN/Inf, and must match the oracle."""
+    M, N, K = 96, 160, 32
+    X, W, H = oracle.gen_problem(M, N, K, seed=2)
+    X[::7, ::5] = 0.0; W[3, :] = 0.0; H[:, 11] = 0.0
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 20, None, 0)
+    assert np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 20, 25)
+    _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr, 1e-5)
+
+
+def test_sharded_w_step_single_gpu_emulation(ng, oracle):
+    """N-sharded W-step emulated on one GPU: two solvers own the two column halves,
+    the host plays the all-reduce on the [Z*H' ; rowsum(H)] buffers."""
+    import ctypes as C
+    M, N, K = 256, 512, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=4)
+    halves = [(0, 200), (200, N)]
+    solvers = []
+    for (a, b) in halves:
+        s = ng.Solver(M, b - a, K, use_graph=False)
+        s.upload(W, np.asfortranarray(H[:, a:b]), np.asfortranarray(X[:, a:b]))
+        solvers.append(s)
+    hip = C.CDLL("libamdhip64.so")
+    for _ in range(5):
+        bufs = []
+        for s in solvers:
+            s.update_h()
+            s.w_partial()
+            s.sync()
+            ptr, cnt = s.partial_buffer()
+            host = np.empty(cnt, np.float32)
+            assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(cnt * 4), 2) == 0
+            bufs.append(host)
+        tot = bufs[0] + bufs[1]
+        for s in solvers:
+            ptr, cnt = s.partial_buffer()
+            assert hip.hipMemcpy(C.c_void_p(ptr), tot.ctypes.data_as(C.c_void_p), C.c_size_t(cnt * 4), 1) == 0
+            s.w_apply()
+    outs = [s.download() for s in solvers]
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 5, 25)
+    assert np.array_equal(outs[0][0], outs[1][0])          # W stays replicated bit-for-bit
+    Hcat = np.concatenate([outs[0][1], outs[1][1]], axis=1)
+    _cmp(oracle, outs[0][0], Hcat, Wr, Hr, 1e-5)
+    for s in solvers:
+        s.close()
+
+
+def test_rccl_single_rank_in_graph(ng, oracle):
+    """in-library RCCL all-reduce captured in the hipGraph, 1-rank communicator"""
+    M, N, K = 256, 384, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=6)
+    comm = ng.Comm(ng.Comm.unique_id(), 0, 1)
+    s = ng.Solver(M, N, K, comm=comm)
+    s.upload(W, H, X)
+    s.iterate(5)
+    kl, _ = s.check()
+    Wg, Hg = s.download()
+    s.close()
+    comm.close()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 5, 25)
+    _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5)
+    assert np.isfinite(kl)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 65536, 256)])
+def test_full_size_properties_cfg3(ng, oracle, M, N, K):
+    """BASELINE config 3 at full size: size-independent properties of the KL multiplicative
+    update.  After a W-step  sum_n (W H)[m,n] == sum_n X[m,n]  for every row m (wherever
+    WH >= EPS); after an H-step  sum_m (W H)[m,n] == sum_m X[m,n]  for every column n; and
+    the KL divergence decreases monotonically.  Plus parity with the oracle after K_par = 2
+    iterations (the CPU needs ~0.55 TFLOP per iteration here)."""
+    rng = np.random.default_rng(0)
+    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    kl0, _ = s.check()
+    s.update_h()
+    W1, H1 = s.download()
+    colsum_wh = (W1.astype(np.float64).sum(axis=0) @ H1.astype(np.float64))
+    assert np.allclose(colsum_wh, np.maximum(X, ng.EPS).astype(np.float64).sum(axis=0), rtol=2e-5)
+    s.update_w()
+    W2, H2 = s.download()
+    rowsum_wh = W2.astype(np.float64) @ H2.astype(np.float64).sum(axis=1)
+    assert np.allclose(rowsum_wh, np.maximum(X, ng.EPS).astype(np.float64).sum(axis=1), rtol=2e-5)
+    kl1, _ = s.check()
+    s.iterate(1)
+    kl2, _ = s.check()
+    assert kl0 > kl1 > kl2 > 0
+    Wg, Hg = s.download()
+    s.close()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 2, 25)
+    print("cfg3 K_par=2 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
