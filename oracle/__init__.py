@@ -31,8 +31,40 @@ def build(native: bool = False) -> str:
     return os.path.join(_HERE, "libnmf_oracle_native.so" if native else "libnmf_oracle.so")
 
 
+def cpu_budget() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup cpu quota).  The GPU box shows all
+    host CPUs but caps the container by quota; an OpenMP team sized to the former thrashes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        n = min(n, int(env))
+    # last resort when the quota is not visible: a 1-GPU box grants about 16 CPUs
+    n = min(n, int(os.environ.get("NMF_ORACLE_MAX_THREADS", "16")))
+    return max(1, n)
+
+
 def _bind(path: str):
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
     lib = C.CDLL(path)
+    lib.oracle_set_num_threads.restype = None
+    lib.oracle_set_num_threads.argtypes = [C.c_int]
+    lib.oracle_set_num_threads(cpu_budget())
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_update_div.restype = C.c_int
     lib.oracle_update_div.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,

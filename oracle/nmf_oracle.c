@@ -25,6 +25,16 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* The GPU box exposes every host CPU but grants a cgroup quota of a few: the Python wrapper
+ * passes the quota here so OpenMP does not oversubscribe it. */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ RNG ------
  * matrix_export.py:4-7 uses numpy's legacy global RandomState: MT19937 seeded by
  * init_genrand(seed); rand() = 53-bit double from two 32-bit outputs; then

@@ -82,6 +82,7 @@ int    oracle_read_bin(const char *path, uint32_t *rows, uint32_t *cols, float *
 int    oracle_write_bin(const char *path, uint32_t rows, uint32_t cols, const float *data);
 
 int    oracle_num_threads(void);
+void   oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }
