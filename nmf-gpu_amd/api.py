@@ -26,7 +26,7 @@ __all__ = [
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmf_mi355x.so")
+LIB_PATH = os.environ.get("NMF_LIB_PATH") or os.path.join(_HERE, "libnmf_mi355x.so")   # override: A/B builds
 EPS = np.float32(2.2204e-16)
 PATH_AUTO, PATH_FUSED, PATH_UNFUSED = 0, 1, 2
 T_NAMES = ["total", "h2d", "h_step", "w_step", "sums", "apply", "check", "allreduce", "d2h", "setup"]

@@ -589,6 +589,11 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
+                if (which >= 100 && which < 164) {   // ablation probes (timing only, clobbers H)
+                    fa.nsplit = 1; fa.partial = 0; fa.U_out = s->H; fa.norm = s->normW;
+                    HIPCHK(launch_fused_probe(fa, which - 100, st));
+                    break;
+                }
                 return NMF_ERR_ARG;
         }
     }

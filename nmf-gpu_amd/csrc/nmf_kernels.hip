@@ -14,6 +14,8 @@
 // cuda/matrix.cu:97-250 (operators), cuda/matrix.cu:505-735 (reductions).
 #include "nmf_kernels.h"
 
+#include <cstdlib>
+
 namespace nmf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,8 +56,10 @@ __device__ __forceinline__ void stage_load(f32x4 (&st)[KT], const float *__restr
         if (!WSTEP) {   // V = W (p contiguous): K rows of 32 floats
             const int k = f >> 3, i4 = f & 7;
             st[q] = *reinterpret_cast<const f32x4 *>(V + (size_t)(p0 + 4 * i4) + (size_t)k * ldv);
-        } else {        // V = H (k contiguous): 32 columns of K floats
-            const int k4 = f % (KT * 8), i = f / (KT * 8);
+        } else {        // V = H (k contiguous): 32 columns of K floats.  8 lanes cover 128 B of one column,
+                        // the next 8 lanes the next column: full lines from HBM and, with the 33-float LDS
+                        // rows, the transposing ds_write_b32 below hit 32 distinct banks.
+            const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31;
             st[q] = *reinterpret_cast<const f32x4 *>(V + (size_t)(4 * k4) + (size_t)(p0 + i) * ldv);
         }
     }
@@ -71,7 +75,7 @@ __device__ __forceinline__ void stage_store(const f32x4 (&st)[KT], float *__rest
 #pragma unroll
             for (int c = 0; c < 4; ++c) vl[k * kLdv + 4 * i4 + c] = st[q][c];
         } else {
-            const int k4 = f % (KT * 8), i = f / (KT * 8);
+            const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31;
 #pragma unroll
             for (int c = 0; c < 4; ++c) vl[(4 * k4 + c) * kLdv + i] = st[q][c];
         }
@@ -103,83 +107,49 @@ __device__ __forceinline__ void load_u(float (&ub)[KT * 16], const float *__rest
     }
 }
 
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+#define NMF_SG_VALU 0x002
+#define NMF_SG_MFMA 0x008
+#define NMF_SG_VMEM_READ 0x020
+#define NMF_SG_DS_READ 0x100
+#define NMF_SG_DS_WRITE 0x200
+
+// Product 1: S(32 p x 32 q) = V_chunk * U_slice, one dependent chain of KT*16 MFMAs (the 32x32x2 f32
+// MFMA has issue interval = dependent latency = 64 cycles, so a single chain runs at full rate as
+// long as its A operand is already in a register).  The A operands come from LDS through a ring of
+// kRing registers loaded kRing MFMAs (>= 512 cycles) ahead of their use; hipcc otherwise emits
+// ds_read -> s_waitcnt lgkmcnt(0) -> MFMA and exposes the LDS latency on every pair.
+constexpr int kRing = 8;
 template <int KT>
 __device__ __forceinline__ f32x16 product1(const float (&ub)[KT * 16], const float *__restrict__ vb, int c, int h) {
+    constexpr int N = KT * 16;
+    constexpr int D = (N < kRing) ? N : kRing;
+    const float *__restrict__ base = vb + h * kLdv + c;   // operand of step ss: base[2*ss*kLdv]
+    float a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) a[i] = base[2 * i * kLdv];
     f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ss = 0; ss < KT * 16; ++ss) s = NMF_MFMA(vb[(2 * ss + h) * kLdv + c], ub[ss], s);
+    for (int ss = 0; ss < N; ++ss) {
+        s = NMF_MFMA(a[ss % D], ub[ss], s);
+        if (ss + D < N) a[ss % D] = base[2 * (ss + D) * kLdv];
+        //__builtin_amdgcn_sched_group_barrier(NMF_SG_MFMA, 1, 0);
+        //__builtin_amdgcn_sched_group_barrier(NMF_SG_DS_READ, 1, 0);
+    }
     return s;
 }
 
+template <int KT>
+__device__ __forceinline__ f32x16 product1_nolds(const float (&ub)[KT * 16], float av) {
+    f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < KT * 16; ++ss) s = NMF_MFMA(av, ub[ss], s);
+    return s;
+}
+
+// Epilogue shared by both kernel versions: lane holds Acc(k = 32t + rho(r) + 4h, q0 + c).
 template <int KT, bool WSTEP, bool PARTIAL>
-__global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KP = KT * 32;
-    constexpr int VBUF = KP * kLdv;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int P = WSTEP ? a.Np : a.Mp;   // streamed / reduced dimension
-    const int Q = WSTEP ? a.Mp : a.Np;   // owned dimension
-    const int nsplit = a.nsplit;
-    const int split = blockIdx.x % nsplit;   // workgroups of one split share the V stream (same XCD under round-robin)
-    const int qblk = blockIdx.x / nsplit;
-    int q0 = (qblk * 4 + wave) * 32;
-    const bool active = q0 < Q;
-    if (!active) q0 = Q - 32;                // tail wave: recompute a valid slice, store nothing
-    const float *__restrict__ V = WSTEP ? a.H : a.W;
-    const float *__restrict__ U = WSTEP ? a.W : a.H;
-    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
-    const int nchunks = P / 32;
-    const int cps = (nchunks + nsplit - 1) / nsplit;
-    const int c_begin = split * cps;
-    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
-
-    float ub[KT * 16];
-    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
-
-    f32x16 acc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    if (c_begin < c_end) {
-        f32x4 st[KT];
-        float xr[16];
-        stage_load<KT, WSTEP>(st, V, ldv, c_begin * 32, tid);
-        load_x<WSTEP>(xr, a.X, ldx, c_begin * 32, q0, c, h);
-        stage_store<KT, WSTEP>(st, smem, tid);
-        __syncthreads();
-        for (int ch = c_begin; ch < c_end; ++ch) {
-            const int par = (ch - c_begin) & 1;
-            const float *__restrict__ vb = smem + par * VBUF;
-            float *__restrict__ vn = smem + (par ^ 1) * VBUF;
-            const bool more = ch + 1 < c_end;
-            if (more) stage_load<KT, WSTEP>(st, V, ldv, (ch + 1) * 32, tid);
-
-            // product 1: S(32 p x 32 q) = V_chunk * U_slice, reduction over K (one dependent MFMA chain)
-            const f32x16 s = product1<KT>(ub, vb, c, h);
-
-            // quotient Z = X ./ max(S, EPS)  (set_epsilon + vec_div, cuda/nmf.cu:128-131)
-            float z[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = xr[r] / clamp_eps(s[r]);
-            if (more) load_x<WSTEP>(xr, a.X, ldx, (ch + 1) * 32, q0, c, h);
-
-            // product 2: Acc(K x 32 q) += V_chunk' * Z, reduction over the chunk's 32 p;
-            // z[r] is the B operand for the k-pair (rho(r), rho(r)+4).
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                for (int t = 0; t < KT; ++t)
-                    acc[t] = NMF_MFMA(vb[(32 * t + c) * kLdv + rho(r) + 4 * h], z[r], acc[t]);
-            }
-            if (more) stage_store<KT, WSTEP>(st, vn, tid);
-            __syncthreads();
-        }
-    }
-    if (!active) return;
-
-    // epilogue: lane holds Acc(k = 32t + rho(r) + 4h, q0 + c)
+__device__ __forceinline__ void fused_epilogue(const FusedArgs &a, const f32x16 (&acc)[KT], int split, int q0, int c, int h, long ldu) {
     if (PARTIAL) {
         const size_t slab = WSTEP ? (size_t)a.Mp * a.Kp : (size_t)a.Kp * a.Np;
         float *__restrict__ out = a.partials + (size_t)split * slab;
@@ -227,29 +197,351 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
     }
 }
 
+// v1: one chunk at a time (product 1, then product 2), two LDS buffers.  Kept for A/B timing
+// (NMF_FUSED_VARIANT=1); the production kernel is fused_step_kernel below.
+// ABL (ablation bitmask, timing probes only; results are garbage when non-zero):
+//   1 = no divide, 2 = MFMA A operands not read from LDS, 4 = no staging / barrier / X loads,
+//   8 = no barrier only, 16 = no X loads only, 32 = no V staging (global load + LDS write) only
+template <int KT, bool WSTEP, bool PARTIAL, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void fused_step_kernel_v1(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = KT * 32;
+    constexpr int VBUF = KP * kLdv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int P = WSTEP ? a.Np : a.Mp;   // streamed / reduced dimension
+    const int Q = WSTEP ? a.Mp : a.Np;   // owned dimension
+    const int nsplit = a.nsplit;
+    const int split = blockIdx.x % nsplit;   // workgroups of one split share the V stream (same XCD under round-robin)
+    const int qblk = blockIdx.x / nsplit;
+    int q0 = (qblk * 4 + wave) * 32;
+    const bool active = q0 < Q;
+    if (!active) q0 = Q - 32;                // tail wave: recompute a valid slice, store nothing
+    const float *__restrict__ V = WSTEP ? a.H : a.W;
+    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
+    const int nchunks = P / 32;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * cps;
+    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
+
+    float ub[KT * 16];
+    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (c_begin < c_end) {
+        f32x4 st[KT];
+        float xr[16];
+        stage_load<KT, WSTEP>(st, V, ldv, c_begin * 32, tid);
+        load_x<WSTEP>(xr, a.X, ldx, c_begin * 32, q0, c, h);
+        stage_store<KT, WSTEP>(st, smem, tid);
+        __syncthreads();
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int par = (ch - c_begin) & 1;
+            const float *__restrict__ vb = smem + par * VBUF;
+            float *__restrict__ vn = smem + (par ^ 1) * VBUF;
+            const bool more = ch + 1 < c_end;
+            if (more && !(ABL & (4 | 32))) stage_load<KT, WSTEP>(st, V, ldv, (ch + 1) * 32, tid);
+
+            // product 1: S(32 p x 32 q) = V_chunk * U_slice, reduction over K
+            const f32x16 s = (ABL & 2) ? product1_nolds<KT>(ub, xr[0]) : product1<KT>(ub, vb, c, h);
+
+            // product 2: Acc(K x 32 q) += V_chunk' * Z with Z = X ./ max(S, EPS) (set_epsilon + vec_div,
+            // cuda/nmf.cu:128-131) taken straight from the accumulator layout: z(r) is the B operand for
+            // the k-pair (rho(r), rho(r)+4).  The IEEE divide of row r+1, the LDS writes of the next
+            // chunk and the operand prefetch are interleaved with the KT independent MFMAs of row r.
+            constexpr int E = 16 * KT;
+            constexpr int D2 = (E < kRing) ? E : kRing;
+            const float *__restrict__ base2 = vb + c * kLdv + 4 * h;   // operand (r,t): base2[32*t*kLdv + rho(r)]
+            float a2[D2];
+#pragma unroll
+            for (int e = 0; e < D2; ++e) a2[e] = (ABL & 2) ? xr[e % 16] : base2[32 * (e % KT) * kLdv + rho(e / KT)];
+            float zc = (ABL & 1) ? xr[0] + s[0] : xr[0] / clamp_eps(s[0]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float zn = 0.f;
+                if (r + 1 < 16) zn = (ABL & 1) ? xr[r + 1] + s[r + 1] : xr[r + 1] / clamp_eps(s[r + 1]);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const int e = r * KT + t;
+                    acc[t] = NMF_MFMA(a2[e % D2], zc, acc[t]);
+                    if (e + D2 < E && !(ABL & 2)) a2[e % D2] = base2[32 * ((e + D2) % KT) * kLdv + rho((e + D2) / KT)];
+                    //__builtin_amdgcn_sched_group_barrier(NMF_SG_MFMA, 1, 0);
+                    //__builtin_amdgcn_sched_group_barrier(NMF_SG_DS_READ, 1, 0);
+                    //__builtin_amdgcn_sched_group_barrier(NMF_SG_VALU, 3, 0);
+                }
+                zc = zn;
+            }
+            if (more && !(ABL & (4 | 16))) load_x<WSTEP>(xr, a.X, ldx, (ch + 1) * 32, q0, c, h);
+            if (more && !(ABL & (4 | 32))) stage_store<KT, WSTEP>(st, vn, tid);
+            if (!(ABL & (4 | 8))) __syncthreads();
+        }
+    }
+    if (!active) return;
+
+    fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
+}
+
+
+// =====================================================================================
+// Production fused half-step: software-pipelined across chunks.
+// In the steady state one loop iteration issues, interleaved in this order,
+//   * product 2 of chunk j   (16 rows x KT independent MFMAs, operands from LDS buffer j),
+//   * product 1 of chunk j+1 (one dependent chain of 16*KT MFMAs, LDS buffer j+1), finished two
+//     rows early so its result is back before the first divide that needs it,
+//   * the IEEE divide of the next row of Z, cut into four stages placed between MFMAs,
+//   * the LDS writes of chunk j+2 (global loads issued at the top of the iteration),
+// so the matrix pipe never waits for an LDS read, a divide or a chunk boundary.  Three LDS buffers,
+// one barrier per chunk.  The translation unit is compiled with the machine scheduler off: the
+// statement order below IS the issue order.
+// =====================================================================================
+struct DivPipe {   // state of one correctly-rounded fp32 division x / y, identical to hipcc's expansion of `/`
+    float x, y, ds, rc, ns, q;
+    bool fl;
+};
+__device__ __forceinline__ void div_stage(int stage, DivPipe &d) {
+    if (stage == 0) {
+        bool unused;
+        d.ds = __builtin_amdgcn_div_scalef(d.x, d.y, false, &unused);
+        d.rc = __builtin_amdgcn_rcpf(d.ds);
+    } else if (stage == 1) {
+        const float e0 = __builtin_fmaf(-d.ds, d.rc, 1.0f);
+        d.rc = __builtin_fmaf(e0, d.rc, d.rc);
+        d.ns = __builtin_amdgcn_div_scalef(d.x, d.y, true, &d.fl);
+    } else if (stage == 2) {
+        d.q = d.ns * d.rc;
+        const float e1 = __builtin_fmaf(-d.ds, d.q, d.ns);
+        d.q = __builtin_fmaf(e1, d.rc, d.q);
+    } else {
+        const float e2 = __builtin_fmaf(-d.ds, d.q, d.ns);
+        const float r = __builtin_amdgcn_div_fmasf(e2, d.rc, d.q, d.fl);
+        d.q = __builtin_amdgcn_div_fixupf(r, d.y, d.x);
+    }
+}
+
+// number of product-1 steps issued once product-2 steps 0..e have been issued
+template <int KT>
+__device__ __forceinline__ constexpr int p1_cum(int e) {
+    constexpr int N = 16 * KT, END = N - 2 * KT;
+    if (e < 0) return 0;
+    const int v = ((e + 1) * N + END - 1) / END;
+    return v < N ? v : N;
+}
+
+template <int KT, bool WSTEP, bool NEXT, bool STORE>
+__device__ __forceinline__ void pipelined_chunk(f32x16 (&acc)[KT], const float (&ub)[KT * 16], const float *__restrict__ vb_cur,
+                                                const float *__restrict__ vb_nxt, float *__restrict__ vb_st, const f32x16 &s_cur,
+                                                f32x16 &s_nxt, const float (&x_cur)[16], const float (&x_nxt)[16], float (&a2)[kRing],
+                                                float &zc, const f32x4 (&st)[KT], int tid, int c, int h) {
+    constexpr int N = 16 * KT;
+    static_assert(N % kRing == 0, "ring must divide the step count");
+    const float *__restrict__ base1 = vb_nxt + h * kLdv + c;        // product-1 operand of step i : base1[2*i*kLdv]
+    const float *__restrict__ base2 = vb_cur + c * kLdv + 4 * h;    // product-2 operand (r,t)     : base2[32*t*kLdv + rho(r)]
+    const float *__restrict__ base2n = vb_nxt + c * kLdv + 4 * h;
+    float a1[kRing];
+    if (NEXT) {
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) a1[i] = base1[2 * i * kLdv];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
+    }
+    DivPipe dv;
+    dv.x = dv.y = dv.ds = dv.rc = dv.ns = dv.q = 0.f;
+    dv.fl = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool have_div = (r + 1 < 16) || NEXT;   // row r+1 of this chunk, or row 0 of the next one
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int e = r * KT + t;
+            if (have_div) {
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    if ((sg * KT) / 4 == t) {
+                        if (sg == 0) {
+                            if (r + 1 < 16) { dv.x = x_cur[r + 1]; dv.y = clamp_eps(s_cur[r + 1]); }
+                            else            { dv.x = x_nxt[0];     dv.y = clamp_eps(s_nxt[0]); }
+                        }
+                        div_stage(sg, dv);
+                    }
+                }
+            }
+            // product 2
+            acc[t] = NMF_MFMA(a2[e % kRing], zc, acc[t]);
+            if (e + kRing < N) {
+                a2[e % kRing] = base2[32 * ((e + kRing) % KT) * kLdv + rho((e + kRing) / KT)];
+            } else if (NEXT) {   // refill the ring with the first operands of the next chunk's product 2
+                const int en = e + kRing - N;
+                a2[e % kRing] = base2n[32 * (en % KT) * kLdv + rho(en / KT)];
+            }
+            // product 1 of the next chunk
+            if (NEXT) {
+#pragma unroll
+                for (int i = p1_cum<KT>(e - 1); i < p1_cum<KT>(e); ++i) {
+                    s_nxt = NMF_MFMA(a1[i % kRing], ub[i], s_nxt);
+                    if (i + kRing < N) a1[i % kRing] = base1[2 * (i + kRing) * kLdv];
+                }
+            }
+            // LDS writes of chunk j+2 (4*KT per thread), one every 2nd slot of the second half of the
+            // chunk: its global loads were issued at the top of the iteration and need ~2 us to land
+            if (STORE && e >= N / 2 && ((e - N / 2) % 2) == 1) {
+                const int w = (e - N / 2) / 2, q = w / 4, cc = w % 4;
+                const int f = tid + q * 256;
+                if (!WSTEP) {
+                    const int k = f >> 3, i4 = f & 7;
+                    vb_st[k * kLdv + 4 * i4 + cc] = st[q][cc];
+                } else {
+                    const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31;
+                    vb_st[(4 * k4 + cc) * kLdv + i] = st[q][cc];
+                }
+            }
+        }
+        if (have_div) zc = dv.q;
+    }
+}
+
+template <int KT, bool WSTEP, bool PARTIAL>
+__global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VBUF = KT * 32 * kLdv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int P = WSTEP ? a.Np : a.Mp;   // streamed / reduced dimension
+    const int Q = WSTEP ? a.Mp : a.Np;   // owned dimension
+    const int nsplit = a.nsplit;
+    const int split = blockIdx.x % nsplit;   // workgroups of one split share the V stream (same XCD under round-robin)
+    const int qblk = blockIdx.x / nsplit;
+    int q0 = (qblk * 4 + wave) * 32;
+    const bool active = q0 < Q;
+    if (!active) q0 = Q - 32;                // tail wave: recompute a valid slice, store nothing
+    const float *__restrict__ V = WSTEP ? a.H : a.W;
+    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
+    const int nchunks = P / 32;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * cps;
+    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
+    const int nch = c_end - c_begin;
+
+    float ub[KT * 16];
+    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (nch > 0) {
+        f32x4 st[KT];
+        float x_cur[16], x_nxt[16];
+        float *b0 = smem, *b1 = smem + VBUF, *b2 = smem + 2 * VBUF;
+        // prologue: chunks 0 and 1 into LDS, product 1 of chunk 0 on its own
+        stage_load<KT, WSTEP>(st, V, ldv, c_begin * 32, tid);
+        load_x<WSTEP>(x_cur, a.X, ldx, c_begin * 32, q0, c, h);
+        stage_store<KT, WSTEP>(st, b0, tid);
+        if (nch > 1) {
+            stage_load<KT, WSTEP>(st, V, ldv, (c_begin + 1) * 32, tid);
+            load_x<WSTEP>(x_nxt, a.X, ldx, (c_begin + 1) * 32, q0, c, h);
+            stage_store<KT, WSTEP>(st, b1, tid);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x_nxt[r] = 0.f;
+        }
+        __syncthreads();
+        f32x16 s_cur = product1<KT>(ub, b0, c, h);
+        f32x16 s_nxt;
+        float a2[kRing];
+        {
+            const float *__restrict__ base2 = b0 + c * kLdv + 4 * h;
+#pragma unroll
+            for (int e = 0; e < kRing; ++e) a2[e] = base2[32 * (e % KT) * kLdv + rho(e / KT)];
+        }
+        float zc = x_cur[0] / clamp_eps(s_cur[0]);
+        for (int j = 0; j + 1 < nch; ++j) {
+            // Branch-free body (a second instantiation inside the loop makes the register allocator copy
+            // every accumulator at the join).  Past the end the chunk index is clamped: the surplus
+            // chunk lands in an LDS buffer / registers nobody reads again.
+            const int cn = (j + 2 < nch) ? (c_begin + j + 2) : (c_end - 1);
+            stage_load<KT, WSTEP>(st, V, ldv, cn * 32, tid);
+            pipelined_chunk<KT, WSTEP, true, true>(acc, ub, b0, b1, b2, s_cur, s_nxt, x_cur, x_nxt, a2, zc, st, tid, c, h);
+            s_cur = s_nxt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x_cur[r] = x_nxt[r];
+            __syncthreads();
+            // after the barrier, so that its vmcnt(0) finds no load of ours in flight
+            load_x<WSTEP>(x_nxt, a.X, ldx, cn * 32, q0, c, h);
+            float *tmp = b0; b0 = b1; b1 = b2; b2 = tmp;
+        }
+        // last chunk: product 2 only
+        pipelined_chunk<KT, WSTEP, false, false>(acc, ub, b0, b1, b2, s_cur, s_nxt, x_cur, x_nxt, a2, zc, st, tid, c, h);
+    }
+    if (!active) return;
+    fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
+}
+
+// Measured on MI355X (cfg3): v1 (chunk-serial) 2.32/2.36 ms H/W, v2 (software-pipelined) 2.38-2.56/2.45 ms:
+// hipcc does not keep v2's intended issue order, so v1 is the default; NMF_FUSED_VARIANT=2 selects v2.
+static int fused_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && e[0] == '2') ? 2 : 1; }
+    return v;
+}
+
 template <int KT>
 static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t stream) {
     const int Q = wstep ? a.Mp : a.Np;
     const int nqblk = (Q + 127) / 128;
     const dim3 grid((unsigned)(nqblk * a.nsplit)), block(256);
-    const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
     const bool partial = a.partial != 0;
-#define NMF_LAUNCH_FUSED(W_, P_)                                                                          \
+    const bool v1 = fused_variant() == 1;
+    const size_t lds = (size_t)(v1 ? 2 : 3) * KT * 32 * kLdv * sizeof(float);
+#define NMF_LAUNCH_FUSED(KERNEL, W_, P_)                                                                  \
     do {                                                                                                  \
         static bool attr_done = false;                                                                    \
         if (!attr_done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)fused_step_kernel<KT, W_, P_>,               \
+            hipError_t e = hipFuncSetAttribute((const void *)KERNEL<KT, W_, P_>,                          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             if (e != hipSuccess) return e;                                                                \
             attr_done = true;                                                                             \
         }                                                                                                 \
-        hipLaunchKernelGGL((fused_step_kernel<KT, W_, P_>), grid, block, lds, stream, a);                 \
+        hipLaunchKernelGGL((KERNEL<KT, W_, P_>), grid, block, lds, stream, a);                            \
     } while (0)
-    if (!wstep && !partial) NMF_LAUNCH_FUSED(false, false);
-    else if (!wstep && partial) NMF_LAUNCH_FUSED(false, true);
-    else if (wstep && !partial) NMF_LAUNCH_FUSED(true, false);
-    else NMF_LAUNCH_FUSED(true, true);
+    if (v1) {
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, false, false);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, false, true);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, true, false);
+        else NMF_LAUNCH_FUSED(fused_step_kernel_v1, true, true);
+    } else {
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel, false, false);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel, false, true);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel, true, false);
+        else NMF_LAUNCH_FUSED(fused_step_kernel, true, true);
+    }
 #undef NMF_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
+// timing probe: v1 H-step kernel (KT = 8, in place) with an ablation mask
+hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream) {
+    if (a.Kp != 256) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.Np + 127) / 128)), block(256);
+    const size_t lds = (size_t)2 * 8 * 32 * kLdv * sizeof(float);
+#define NMF_PROBE(A_)                                                                                                   \
+    case A_:                                                                                                            \
+        (void)hipFuncSetAttribute((const void *)fused_step_kernel_v1<8, false, false, A_>,                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+        hipLaunchKernelGGL((fused_step_kernel_v1<8, false, false, A_>), grid, block, lds, stream, a);                   \
+        break;
+    switch (abl) {
+        NMF_PROBE(0) NMF_PROBE(1) NMF_PROBE(2) NMF_PROBE(3) NMF_PROBE(4) NMF_PROBE(5) NMF_PROBE(6) NMF_PROBE(7)
+        NMF_PROBE(8) NMF_PROBE(16) NMF_PROBE(32) NMF_PROBE(24) NMF_PROBE(40) NMF_PROBE(48) NMF_PROBE(11) NMF_PROBE(19) NMF_PROBE(35)
+        default: return hipErrorInvalidValue;
+    }
+#undef NMF_PROBE
     return hipGetLastError();
 }
 
@@ -460,10 +752,10 @@ hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *o
     return hipGetLastError();
 }
 
-constexpr int kRowSumCols = 256;   // columns per workgroup in level 1
+constexpr int kRowSumCols = 64;   // columns per workgroup in level 1 (>= 1024 workgroups at N = 65536)
 int row_sum_blocks(int cols) { return (cols + kRowSumCols - 1) / kRowSumCols; }
 
-// level 1: part[b*rows + k] = sum over this block's columns of A[k + col*ld]
+// level 1: part[b*rows + k] = sum over this block's columns of A[k + col*ld]; fixed order per (b, k)
 __global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restrict__ A, int rows, int cols, long ld, float *__restrict__ part) {
     __shared__ float red[256];
     const int c0 = blockIdx.x * kRowSumCols;
@@ -471,9 +763,15 @@ __global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restric
     float *__restrict__ outp = part + (size_t)blockIdx.x * rows;
     if (rows >= 256) {
         for (int k = threadIdx.x; k < rows; k += 256) {
-            float s = 0.f;
-            for (int col = c0; col < c1; ++col) s += A[(size_t)k + (size_t)col * ld];
-            outp[k] = s;
+            const float *__restrict__ a = A + (size_t)k;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains keep loads in flight
+            int col = c0;
+            for (; col + 4 <= c1; col += 4) {
+                s0 += a[(size_t)(col + 0) * ld]; s1 += a[(size_t)(col + 1) * ld];
+                s2 += a[(size_t)(col + 2) * ld]; s3 += a[(size_t)(col + 3) * ld];
+            }
+            for (; col < c1; ++col) s0 += a[(size_t)col * ld];
+            outp[k] = (s0 + s1) + (s2 + s3);
         }
     } else {
         const int nsub = 256 / rows;             // column phases handled in parallel
@@ -490,20 +788,32 @@ __global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restric
         }
     }
 }
-// level 2: out[k] = sum_b part[b*rows + k]
-__global__ __launch_bounds__(256) void row_sums_l2_kernel(const float *__restrict__ part, int rows, int nblk, float *__restrict__ out, int clamp) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= rows) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * rows + k];
-    out[k] = clamp ? clamp_eps(s) : s;
+// level 2: out[k] = sum_b part[b*rows + k].  One workgroup per 32 rows; 32 groups of 32 lanes stride
+// over the partial blocks, then a fixed-order LDS combine.
+__global__ __launch_bounds__(1024) void row_sums_l2_kernel(const float *__restrict__ part, int rows, int nblk, float *__restrict__ out, int clamp) {
+    __shared__ float red[32][33];
+    const int kl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kl;
+    float s0 = 0.f, s1 = 0.f;
+    if (k < rows) {
+        int b = g;
+        for (; b + 32 < nblk; b += 64) { s0 += part[(size_t)b * rows + k]; s1 += part[(size_t)(b + 32) * rows + k]; }
+        if (b < nblk) s0 += part[(size_t)b * rows + k];
+    }
+    red[g][kl] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && k < rows) {
+        float tot = 0.f;
+        for (int q = 0; q < 32; ++q) tot += red[q][kl];
+        out[k] = clamp ? clamp_eps(tot) : tot;
+    }
 }
 hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp, hipStream_t stream) {
     const int nblk = row_sum_blocks(cols);
     hipLaunchKernelGGL(row_sums_l1_kernel, dim3(nblk), dim3(256), 0, stream, A, rows, cols, ld, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(row_sums_l2_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, part, rows, nblk, out, clamp ? 1 : 0);
+    hipLaunchKernelGGL(row_sums_l2_kernel, dim3((rows + 31) / 32), dim3(1024), 0, stream, part, rows, nblk, out, clamp ? 1 : 0);
     return hipGetLastError();
 }
 
