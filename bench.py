@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="rehearsal only: gloo lets several ranks share one GPU (with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,12 +95,17 @@ def main():
     ng.lib()   # fail loudly if the HIP library is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     M, Nloc, K = args.M, args.N, args.K
     Ntot = Nloc * world
@@ -109,7 +117,7 @@ def main():
     H = synth(2000 + rank, K, Nloc)
 
     comm = None
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 and args.comm == "torch" else None
+    shard = None
     if world > 1 and args.comm == "rccl":
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
@@ -117,24 +125,21 @@ def main():
         uid = uid.cuda()
         dist.broadcast(uid, 0)
         comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-    s = ng.Solver(M, Nloc, K, use_graph=not args.no_graph, device=local_rank, stream=stream, comm=comm)
+    if world > 1 and args.comm == "torch":
+        # half-step protocol + torch.distributed all-reduce of the (M*K + K)-float partial buffer
+        shard = ng.GpuShard(M, Nloc, K, device=local_rank)
+        s = shard.solver
+        loop = ng.ShardedLoop(shard, lambda t: dist.all_reduce(t), None)
+    else:
+        s = ng.Solver(M, Nloc, K, use_graph=not args.no_graph, device=local_rank, comm=comm)
     s.upload(W, H, X)
     del X
-    pbuf = None
-    if world > 1 and args.comm == "torch":
-        _, cnt = s.partial_buffer()
-        pbuf = torch.zeros(cnt, dtype=torch.float32, device="cuda")
-        s.set_partial_buffer(pbuf.data_ptr(), cnt)
 
     def step(n):
-        if pbuf is None:
+        if shard is None:
             s.iterate(n)
         else:
-            for _ in range(n):
-                s.update_h()
-                s.w_partial()
-                dist.all_reduce(pbuf)        # RCCL over xGMI, (M*K + K) floats
-                s.w_apply()
+            loop.iterate(n)
 
     def fence():
         s.sync()
@@ -183,7 +188,7 @@ def main():
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
                                    + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {args.comm})" if world > 1 else " (BASELINE config 3)"),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
-                       "hipgraph": (not args.no_graph) and pbuf is None,
+                       "hipgraph": (not args.no_graph) and shard is None,
                        "parallelism": f"N-sharded x{world}" if world > 1 else "single GPU"},
             "frac_of_fp32_mfma_peak": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
             "kl_before": kl0, "kl_after": kl1,

@@ -171,6 +171,8 @@ int  nmf_solver_update_w(nmf_solver *s);
 /* KL(X || W*H) and rel-L1 of the current state; synchronises.  In a sharded run the values
  * are summed over ranks. */
 int  nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1);
+/* the three raw sums behind the check: {KL, sum|X-WH|, sum|X|}; local to this rank unless opts->comm is set */
+int  nmf_solver_check_sums(nmf_solver *s, double sums[3]);
 /* full loop with convergence logic; fills res (may be NULL) */
 int  nmf_solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, int verbose, nmf_result *res);
 int  nmf_solver_sync(nmf_solver *s);

@@ -92,6 +92,7 @@ _SIGS = [
     ("nmf_solver_update_h", C.c_int, [C.c_void_p]),
     ("nmf_solver_update_w", C.c_int, [C.c_void_p]),
     ("nmf_solver_check", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("nmf_solver_check_sums", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("nmf_solver_run", C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(_result)]),
     ("nmf_solver_sync", C.c_int, [C.c_void_p]),
     ("nmf_solver_time_piece", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -413,6 +414,11 @@ class Solver:
         kl, rl1 = C.c_double(), C.c_double()
         _chk(lib().nmf_solver_check(self._h, C.byref(kl), C.byref(rl1)))
         return kl.value, rl1.value
+
+    def check_sums(self):
+        v = (C.c_double * 3)()
+        _chk(lib().nmf_solver_check_sums(self._h, v))
+        return v[0], v[1], v[2]
 
     def run(self, thresh: float = 0.0, max_iter: int = 200, iter_check: int = 25, verbose: int = 0) -> dict:
         r = _result()

@@ -485,8 +485,8 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
 }
 
 // KL / rel-L1 of the current state (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640)
-extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
-    if (!s) return NMF_ERR_ARG;
+extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) {
+    if (!s || !sums) return NMF_ERR_ARG;
     hipStream_t st = s->stream;
     {
         PieceScope p(s, NMF_T_CHECK);
@@ -503,8 +503,14 @@ extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
     }
     HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (kl) *kl = s->chk_host[0];
-    if (rel_l1) *rel_l1 = (s->chk_host[2] > 0.0) ? s->chk_host[1] / s->chk_host[2] : 0.0;
+    sums[0] = s->chk_host[0]; sums[1] = s->chk_host[1]; sums[2] = s->chk_host[2];
+    return NMF_OK;
+}
+extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
+    double v[3];
+    NMFCHK(nmf_solver_check_sums(s, v));
+    if (kl) *kl = v[0];
+    if (rel_l1) *rel_l1 = (v[2] > 0.0) ? v[1] / v[2] : 0.0;
     return NMF_OK;
 }
 

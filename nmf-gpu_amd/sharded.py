@@ -1,0 +1,129 @@
+"""N-sharded update_div: one process per GPU, rank g owns the column block J_g of X
+and H plus a full copy of W.  The H half-step is local; the W half-step needs one sum all-reduce
+per iteration of the (M*K + K)-float buffer [Z_g * H_g' ; rowsum(H_g)], after which every rank
+applies the same update and W stays replicated bit for bit.  New relative to the reference
+(single GPU, no NCCL/MPI anywhere in cuda/).
+
+This module is host logic only: it drives any *backend* exposing the half-step protocol
+
+    update_h()                      local H half-step                      (cuda/nmf.cu:118-146)
+    w_partial() -> buffer           leaves the partial buffer ready        (first half of 148-176)
+    w_apply()                       W *= psum / max(hsum, EPS)             (second half)
+    check_local() -> (kl, sum|x-y|, sum|x|)
+
+and an ``allreduce_sum(buffer)`` callable.  The GPU backend is :class:`GpuShard` (the HIP solver
+with a torch tensor as the all-reduce operand); tests drive the same loop with a CPU backend
+over gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+
+def column_shards(N: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous column blocks [start, stop) per rank; the first N % world ranks get one extra
+    column.  Every rank must own at least one column."""
+    if world < 1 or N < world:
+        raise ValueError(f"cannot shard {N} columns over {world} ranks")
+    base, extra = divmod(N, world)
+    out, start = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < extra else 0)
+        out.append((start, start + cnt))
+        start += cnt
+    return out
+
+
+def worth_sharding(M: int, N: int, K: int, world: int) -> bool:
+    """north_star: shard 'only where N is large enough to amortise the all-reduce'.  Per-GPU compute
+    per iteration is 8*M*(N/world)*K flop at ~1e14 flop/s; the all-reduce moves 4*(M*K+K) bytes at
+    ~1e11 B/s per xGMI link plus ~20 us of latency.  Shard when compute >= 4x that."""
+    if world <= 1:
+        return False
+    compute_s = 8.0 * M * (N / world) * K / 1.0e14
+    comm_s = 2.0 * 4.0 * (M * K + K) / 1.0e11 + 20e-6
+    return compute_s >= 4.0 * comm_s
+
+
+class ShardedLoop:
+    """The update_div loop of one rank (README.md:40-54 contract; checks are summed over ranks)."""
+
+    def __init__(self, backend, allreduce_sum: Callable, allreduce_scalars: Callable):
+        self.b = backend
+        self.allreduce_sum = allreduce_sum            # in-place sum over ranks of the partial buffer
+        self.allreduce_scalars = allreduce_scalars    # list[float] -> list[float], summed over ranks
+
+    def iterate(self, iters: int = 1) -> None:
+        for _ in range(iters):
+            self.b.update_h()
+            buf = self.b.w_partial()
+            self.allreduce_sum(buf)
+            self.b.w_apply()
+
+    def check(self):
+        kl, d, a = self.allreduce_scalars(list(self.b.check_local()))
+        return kl, (d / a if a > 0 else 0.0)
+
+    def run(self, thresh: float = 0.0, max_iter: int = 200, iter_check: int = 25, verbose: int = 0, rank: int = 0):
+        """Same convergence logic as nmf_solver_run / update_div."""
+        checks = thresh > 0 or verbose
+        kls = []
+        prev = 0.0
+        if checks:
+            prev, rl1 = self.check()
+            kls.append(prev)
+        it = 0
+        while it < max_iter:
+            n = max_iter - it
+            if checks:
+                n = min(n, iter_check - (it % iter_check))
+            self.iterate(n)
+            it += n
+            if checks and it % iter_check == 0:
+                cur, rl1 = self.check()
+                kls.append(cur)
+                if verbose and rank == 0:
+                    print(f"iter {it:5d}  kl-divergence {cur:.6e}  rel-L1 error {rl1:.6e}")
+                stop = thresh > 0 and (prev - cur) / prev < thresh
+                prev = cur
+                if stop:
+                    break
+        return it, kls
+
+
+class GpuShard:
+    """Backend over the HIP solver.  The partial buffer is a torch tensor so that
+    torch.distributed (backend "nccl" = RCCL over xGMI) can all-reduce it in place; the solver
+    runs on torch's current stream so the collective is ordered after w_partial()."""
+
+    def __init__(self, M: int, N_local: int, K: int, device: int = 0, **solver_kw):
+        import torch
+        from .api import Solver
+        self.torch = torch
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.solver = Solver(M, N_local, K, device=device, stream=stream, use_graph=False, **solver_kw)
+        _, cnt = self.solver.partial_buffer()
+        self.buf = torch.zeros(cnt, dtype=torch.float32, device=f"cuda:{device}")
+        self.solver.set_partial_buffer(self.buf.data_ptr(), cnt)
+
+    def upload(self, W, H_local, X_local):
+        self.solver.upload(W, H_local, X_local)
+
+    def update_h(self):
+        self.solver.update_h()
+
+    def w_partial(self):
+        self.solver.w_partial()
+        return self.buf
+
+    def w_apply(self):
+        self.solver.w_apply()
+
+    def check_local(self):
+        return self.solver.check_sums()
+
+    def download(self):
+        return self.solver.download()
+
+    def close(self):
+        self.solver.close()

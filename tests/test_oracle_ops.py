@@ -1,0 +1,72 @@
+"""The oracle's building blocks against fp64 numpy (no GPU)."""
+import numpy as np
+import pytest
+
+
+def _rand(shape, seed):
+    return np.asfortranarray(np.random.default_rng(seed).random(shape, dtype=np.float32))
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (5, 7, 3), (64, 64, 64), (130, 33, 257), (1024, 350, 128)])
+def test_sgemms(oracle, m, n, k):
+    A, B = _rand((m, k), 1), _rand((k, n), 2)
+    assert oracle.relF(oracle.sgemm("nn", A, B), A.astype(np.float64) @ B.astype(np.float64)) < 1e-6
+    At = np.asfortranarray(A.T)
+    assert oracle.relF(oracle.sgemm("tn", At, B), A.astype(np.float64) @ B.astype(np.float64)) < 1e-6
+    Bt = np.asfortranarray(B.T)
+    assert oracle.relF(oracle.sgemm("nt", A, Bt), A.astype(np.float64) @ B.astype(np.float64)) < 1e-6
+
+
+def test_sums_and_refcompat_subset(oracle):
+    A = _rand((4096, 9), 3)
+    assert np.allclose(oracle.sum_cols(A), A.astype(np.float64).sum(axis=0), rtol=2e-6)
+    assert np.allclose(oracle.sum_rows(A), A.astype(np.float64).sum(axis=1), rtol=2e-6)
+    S = [0, 1, 2, 4, 8, 16, 32, 64, 65, 66, 68, 72, 80, 96]
+    mask = np.isin(np.arange(4096) % 128, S)
+    assert np.allclose(oracle.sum_cols(A, refcompat=True), A[mask].astype(np.float64).sum(axis=0), rtol=2e-6)
+
+
+def test_clamp_and_kl(oracle):
+    a = np.asfortranarray(np.array([[0.0, 1e-20, 2.2204e-16, 0.5, -3.0, np.nan]], dtype=np.float32))
+    c = oracle.clamp(a)
+    assert c[0, 0] == oracle.EPS and c[0, 1] == oracle.EPS and c[0, 3] == 0.5 and c[0, 4] == oracle.EPS
+    assert np.isnan(c[0, 5])
+    X, Y = _rand((50, 60), 4) + 1e-3, _rand((50, 60), 5) + 1e-3
+    x, y = X.astype(np.float64), Y.astype(np.float64)
+    assert abs(oracle.kl_div(X, Y) - float((x * (np.log(x) - np.log(y)) - x + y).sum())) < 1e-9 * X.size
+    assert abs(oracle.rel_l1(X, Y) - float(np.abs(x - y).sum() / np.abs(x).sum())) < 1e-12
+    assert oracle.kl_div(X, X) == 0.0
+
+
+def test_half_steps_match_numpy_model(oracle):
+    """update_h / update_w (cuda/nmf.cu:118-176) against the MATLAB one-liners of cuda/nmf.cu:104-107."""
+    M, N, K = 96, 70, 12
+    X, W, H = oracle.gen_problem(M, N, K, seed=3)
+    x, w, h = (a.astype(np.float64) for a in (X, W, H))
+    eps = float(oracle.EPS)
+    z = x / np.maximum(w @ h, eps)
+    h1 = h * (w.T @ z) / np.maximum(w.sum(axis=0), eps)[:, None]
+    assert oracle.relF(oracle.update_h(W, H, X), h1) < 1e-6
+    z = x / np.maximum(w @ h, eps)
+    w1 = w * (z @ h.T) / np.maximum(h.sum(axis=1), eps)[None, :]
+    assert oracle.relF(oracle.update_w(W, H, X), w1) < 1e-6
+
+
+def test_convergence_contract(oracle):
+    """README.md:51: stop when (prev-cur)/prev < thresh at a check; thresh == 0 never stops early."""
+    X, W, H = oracle.gen_problem(64, 80, 8, seed=1)
+    _, _, it0, kl0 = oracle.update_div(W, H, X, 0.0, 60, 25)
+    assert it0 == 60 and len(kl0) == 3
+    _, _, it1, kl1 = oracle.update_div(W, H, X, 0.5, 1000, 25)
+    assert it1 % 25 == 0 and it1 < 1000
+    assert (kl1[-2] - kl1[-1]) / kl1[-2] < 0.5
+
+
+def test_bin_roundtrip(oracle, tmp_path):
+    A = _rand((13, 7), 6)
+    p = str(tmp_path / "a.bin")
+    oracle.write_bin(p, A)
+    with open(p, "rb") as f:
+        raw = f.read()
+    assert raw[:8] == np.array([13, 7], dtype=np.uint32).tobytes() and len(raw) == 8 + 13 * 7 * 4
+    assert np.array_equal(oracle.read_bin(p), A)
