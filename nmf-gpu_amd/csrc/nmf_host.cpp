@@ -595,7 +595,11 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
-                if (which >= 100 && which < 164) {   // ablation probes (timing only, clobbers H)
+                if (which >= 1000 && which < 1100) {   // MFMA co-issue micro-probe: nv = which % 10, kind = (which - 1000) / 10
+                    HIPCHK(launch_mfma_valu_probe((which - 1000) % 10, (which - 1000) / 10, s->psum, 2000, st));
+                    break;
+                }
+                if (which >= 100 && which < 228) {   // ablation probes (timing only, clobbers H)
                     fa.nsplit = 1; fa.partial = 0; fa.U_out = s->H; fa.norm = s->normW;
                     HIPCHK(launch_fused_probe(fa, which - 100, st));
                     break;

@@ -261,6 +261,15 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v1(FusedArgs a) {
 #pragma unroll
             for (int e = 0; e < D2; ++e) a2[e] = (ABL & 2) ? xr[e % 16] : base2[32 * (e % KT) * kLdv + rho(e / KT)];
             float zc = (ABL & 1) ? xr[0] + s[0] : xr[0] / clamp_eps(s[0]);
+            if (ABL & 64) {   // probe: product 2 as KT chains of 16 dependent MFMAs instead of round-robin
+                float zz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zz[r] = xr[r] + s[r];
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t] = NMF_MFMA(xr[(r + t) % 16], zz[r], acc[t]);
+            } else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float zn = 0.f;
@@ -399,6 +408,9 @@ __device__ __forceinline__ void pipelined_chunk(f32x16 (&acc)[KT], const float (
                     vb_st[(4 * k4 + cc) * kLdv + i] = st[q][cc];
                 }
             }
+            // pin the issue order: without this fence hipcc's instruction selection clusters the
+            // product-1 MFMAs and sinks the LDS reads next to their uses
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (have_div) zc = dv.q;
     }
@@ -538,11 +550,62 @@ hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream) {
         break;
     switch (abl) {
         NMF_PROBE(0) NMF_PROBE(1) NMF_PROBE(2) NMF_PROBE(3) NMF_PROBE(4) NMF_PROBE(5) NMF_PROBE(6) NMF_PROBE(7)
-        NMF_PROBE(8) NMF_PROBE(16) NMF_PROBE(32) NMF_PROBE(24) NMF_PROBE(40) NMF_PROBE(48) NMF_PROBE(11) NMF_PROBE(19) NMF_PROBE(35)
+        NMF_PROBE(8) NMF_PROBE(16) NMF_PROBE(32) NMF_PROBE(24) NMF_PROBE(40) NMF_PROBE(48) NMF_PROBE(11) NMF_PROBE(19) NMF_PROBE(35) NMF_PROBE(71)
         default: return hipErrorInvalidValue;
     }
 #undef NMF_PROBE
     return hipGetLastError();
+}
+
+
+// Micro-probe: which instruction kinds does a lone wave per SIMD overlap with a running f32 MFMA?
+// KIND 0 = v_add_f32 (VALU), 1 = ds_read_b32 (LDS), 2 = s_add_u32 (SALU), 3 = global_load_dword (VMEM),
+// 4 = v_accvgpr_read (VALU move), 5 = ds_write_b32.  NV instructions of that kind after every MFMA.
+template <int NV, int KIND>
+__global__ __launch_bounds__(256, 1) void mfma_mix_probe_kernel(float *out, int iters) {
+    __shared__ float lds[1024];
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    lds[threadIdx.x] = 1.0f;
+    __syncthreads();
+    float a = (float)threadIdx.x, b = 1.0f;
+    float d[4] = {1.f, 2.f, 3.f, 4.f};
+    unsigned sx = 0;
+    const unsigned laddr = (threadIdx.x & 255) * 4;
+    const float *gp = out + 65536 + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            acc[i & 7] = NMF_MFMA(a, b, acc[i & 7]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (KIND == 0) asm volatile("v_add_f32 %0, %0, %0" : "+v"(d[v & 3]));
+                if (KIND == 1) asm volatile("ds_read_b32 %0, %1" : "=v"(d[v & 3]) : "v"(laddr));
+                if (KIND == 2) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx));
+                if (KIND == 3) asm volatile("global_load_dword %0, %1, off" : "=v"(d[v & 3]) : "v"(gp));
+                if (KIND == 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d[v & 3]) : "a"(acc[7][v & 3]));
+                if (KIND == 5) asm volatile("ds_write_b32 %0, %1" :: "v"(laddr), "v"(d[v & 3]));
+            }
+            if ((KIND == 1 || KIND == 3 || KIND == 5) && (i & 7) == 7) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    float sum = d[0] + d[1] + d[2] + d[3] + (float)sx;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum += acc[t][0];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+hipError_t launch_mfma_valu_probe(int nv, int kind, float *out, int iters, hipStream_t stream) {
+#define NMF_MP2(NV_, K_) if (nv == NV_ && kind == K_) { hipLaunchKernelGGL((mfma_mix_probe_kernel<NV_, K_>), dim3(256), dim3(256), 0, stream, out, iters); return hipGetLastError(); }
+#define NMF_MP(K_) NMF_MP2(0, K_) NMF_MP2(1, K_) NMF_MP2(2, K_) NMF_MP2(4, K_)
+    NMF_MP(0) NMF_MP(1) NMF_MP(2) NMF_MP(3) NMF_MP(4) NMF_MP(5)
+#undef NMF_MP
+#undef NMF_MP2
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
