@@ -595,6 +595,24 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
+                if (which == 3000) {   // in-kernel stamps of the v3 H-step: prints the per-chunk segment cycles
+                    fa.nsplit = 1; fa.partial = 0; fa.U_out = s->H; fa.norm = s->normW; fa.partials = s->partials;
+                    HIPCHK(launch_fused_stamp(fa, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    const int nw = ((s->Np + 127) / 128) * 4;
+                    std::vector<unsigned long long> h((size_t)nw * 7);
+                    HIPCHK(hipMemcpy(h.data(), s->partials, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    double seg[7] = {0, 0, 0, 0, 0, 0, 0};
+                    for (int w = 0; w < nw; ++w) for (int q = 0; q < 7; ++q) seg[q] += (double)h[(size_t)w * 7 + q];
+                    const double nchunk = (double)nw * (s->Mp / 32);
+                    fprintf(stderr, "stamps (s_memtime ticks per chunk, mean over %d waves): head %.0f | product1 %.0f | divide+relayout %.0f | product2 rows 0-11 %.0f | stage_store %.0f | rows 12-15 %.0f | barrier %.0f\n",
+                            nw, seg[0] / nchunk, seg[1] / nchunk, seg[2] / nchunk, seg[3] / nchunk, seg[5] / nchunk, seg[6] / nchunk, seg[4] / nchunk);
+                    break;
+                }
+                if (which >= 2000 && which < 2003) {   // two-waves-per-SIMD partner probe
+                    HIPCHK(launch_mfma_partner_probe(which - 2000, s->psum, 2000, st));
+                    break;
+                }
                 if (which >= 1000 && which < 1100) {   // MFMA co-issue micro-probe: nv = which % 10, kind = (which - 1000) / 10
                     HIPCHK(launch_mfma_valu_probe((which - 1000) % 10, (which - 1000) / 10, s->psum, 2000, st));
                     break;

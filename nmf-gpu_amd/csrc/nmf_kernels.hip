@@ -495,11 +495,241 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
     fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
 }
 
-// Measured on MI355X (cfg3): v1 (chunk-serial) 2.32/2.36 ms H/W, v2 (software-pipelined) 2.38-2.56/2.45 ms:
-// hipcc does not keep v2's intended issue order, so v1 is the default; NMF_FUSED_VARIANT=2 selects v2.
+// =====================================================================================
+// v3: the production fused half-step.  Same chunk-serial structure as v1, rebuilt around what the
+// micro-probes (launch_mfma_valu_probe) measured for a lone wave per SIMD next to f32 MFMAs:
+//   * VALU and VMEM issue is NOT hidden (+4..5 cycles per VALU, +~13 for the first of a group,
+//     +~20 per coalesced global load, hundreds for a lane-strided one),
+//   * ds_read / ds_write / SALU issue IS hidden.
+// Hence: no per-read LDS address arithmetic (one base VGPR + 16-bit immediate offsets, reads kept
+// single by `volatile`), all divides of a chunk in one VALU block, the X tile fetched with four
+// fully coalesced 16-B loads and re-laid into the accumulator layout through a private LDS patch,
+// global addresses as uniform base + 32-bit lane offset.
+// =====================================================================================
+constexpr int kXtLd = 36;                       // X patch row stride in floats (16-B aligned, b128 conflict-free)
+constexpr int kXtFloats = 32 * kXtLd;           // per wave
+
+// LDS pointer with its address space spelled out: a volatile load through a generic pointer is not
+// rewritten by address-space inference and would become flat_load + 64-bit address arithmetic.
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ float lds_ld(const lds_float *p) { return *reinterpret_cast<const volatile lds_float *>(p); }
+
+// DIV = 0: correctly rounded IEEE division (hipcc's expansion of `/`, 11 VALU);
+// DIV = 1: reciprocal refined to <= 1 ulp (rcp, 2 fma, mul, 2 fma; no scaling: y >= EPS is normal here)
+template <int DIV>
+__device__ __forceinline__ float quotient(float x, float y) {
+    if (DIV == 0) return x / y;
+    float r = __builtin_amdgcn_rcpf(y);
+    r = __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+}
+
+// STAMP = true: diagnostic build only (never the shipped path): s_memtime stamps around the five segments of a
+// chunk, summed per wave and written to a.partials as 5 x uint64 per wave; the results of the step stay valid.
+#define NMF_STAMP(var)                                                                                     \
+    do {                                                                                                   \
+        if (STAMP) {                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                        \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+    } while (0)
+template <int KT, bool WSTEP, bool PARTIAL, int DIV, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VBUF = KT * 32 * kLdv;
+    constexpr int N1 = KT * 16;
+    constexpr int D = (N1 < kRing) ? N1 : kRing;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int P = WSTEP ? a.Np : a.Mp;   // streamed / reduced dimension
+    const int Q = WSTEP ? a.Mp : a.Np;   // owned dimension
+    const int nsplit = a.nsplit;
+    const int split = blockIdx.x % nsplit;
+    const int qblk = blockIdx.x / nsplit;
+    int q0 = (qblk * 4 + wave) * 32;     // wave-uniform (SGPR)
+    const bool active = q0 < Q;
+    if (!active) q0 = Q - 32;
+    const float *__restrict__ V = WSTEP ? a.H : a.W;
+    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
+    const int nchunks = P / 32;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * cps;
+    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
+
+    float ub[KT * 16];
+    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (c_begin < c_end) {
+        // ---- per-thread constants: 32-bit lane offsets (floats) from wave-uniform chunk bases
+        // V staging: H-step rows k = (tid>>3) + 32q, 16-B piece i4 = tid&7; W-step column i = (tid>>3)&31, piece k4 = 8q + (tid&7)
+        // (byte offsets: "uniform pointer + zext(32-bit VGPR)" is the form hipcc turns into global_load ... saddr,
+        //  i.e. no per-load 64-bit VALU address arithmetic)
+        const unsigned voff0 = 4u * (WSTEP ? (unsigned)(4 * (tid & 7)) + (unsigned)((tid >> 3) & 31) * (unsigned)ldv
+                                           : (unsigned)(4 * (tid & 7)) + (unsigned)(tid >> 3) * (unsigned)ldv);
+        const unsigned vstep = 4u * (WSTEP ? 32u : 32u * (unsigned)ldv);              // bytes per q (32-bit on purpose)
+        const size_t vchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldv : (size_t)32);   // bytes per chunk
+        // X tile: 32 rows of 128 B; row = (lane>>3) + 8i at stride ldx, 16-B piece lane&7
+        const unsigned xoff0 = 4u * ((unsigned)(4 * (lane & 7)) + (unsigned)(lane >> 3) * (unsigned)ldx);
+        const unsigned xstep = 4u * 8u * (unsigned)ldx;                              // bytes per i (32-bit on purpose)
+        const char *__restrict__ xbase = reinterpret_cast<const char *>(WSTEP ? a.X + (size_t)q0 : a.X + (size_t)q0 * (size_t)ldx);
+        const size_t xchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldx : (size_t)32);
+        float *__restrict__ xt = smem + 2 * VBUF + wave * kXtFloats;          // this wave's X patch
+        float *__restrict__ xt_w = xt + (lane >> 3) * kXtLd + 4 * (lane & 7); // write position (+ 8i rows)
+        const float *__restrict__ xt_r = WSTEP ? xt + 4 * h * kXtLd + c       // + rho(r) rows
+                                               : xt + c * kXtLd + 4 * h;      // + 8g floats
+        // LDS operand bases (floats) inside a V buffer
+        const int p1_off = h * kLdv + c;          // product 1: + 2*ss*kLdv
+        const int p2_off = c * kLdv + 4 * h;      // product 2: + 32*t*kLdv + rho(r)
+
+        f32x4 st[KT];
+        f32x4 xg[4];
+        float xr[16];
+        // one global load per call, so that the loop can space them out between MFMAs: a burst of 1-KiB loads from
+        // all four waves saturates the CU's ~70 B/clk vector-memory path and stalls every wave in issue (~730 cycles
+        // per chunk measured); one load per several MFMAs costs ~22 cycles each.
+        // The lane offsets are made opaque per chunk: otherwise their zero-extension is hoisted out of the loop and
+        // each load needs a v_lshl_add_u64 instead of the global_load ... v_off32, s[base] form.
+        unsigned vo = voff0, xo = xoff0;
+        const char *__restrict__ vcur = reinterpret_cast<const char *>(V);
+        const char *__restrict__ xcur = xbase;
+        auto set_chunk = [&](int ch) {
+            vo = voff0; xo = xoff0;
+            asm volatile("" : "+v"(vo), "+v"(xo));
+            vcur = reinterpret_cast<const char *>(V) + (size_t)ch * vchunk;
+            xcur = xbase + (size_t)ch * xchunk;
+        };
+        auto stage_load_one = [&](int q) { st[q] = *reinterpret_cast<const f32x4 *>((vcur + (size_t)q * (size_t)vstep) + vo); };
+        auto x_load_one = [&](int i) { xg[i] = *reinterpret_cast<const f32x4 *>((xcur + (size_t)i * (size_t)xstep) + xo); };
+        // one 4-byte LDS write of the staged chunk (piece w of 4*KT per thread)
+        auto stage_store_one = [&](float *__restrict__ vl, int w) {
+            const int q = w / 4, cc = w % 4;
+            if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
+            else        { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
+        };
+        auto x_relayout = [&]() {   // xg (coalesced layout) -> LDS patch -> xr (accumulator layout); same wave, DS ops are in order
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(xt_w + 8 * i * kXtLd) = xg[i];
+            if (!WSTEP) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xt_r + 8 * g);
+                    xr[4 * g] = v[0]; xr[4 * g + 1] = v[1]; xr[4 * g + 2] = v[2]; xr[4 * g + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[r] = xt_r[rho(r) * kXtLd];
+            }
+        };
+
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0, seg[7] = {0, 0, 0, 0, 0, 0, 0};
+        set_chunk(c_begin);
+#pragma unroll
+        for (int q = 0; q < KT; ++q) stage_load_one(q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x_load_one(i);
+        stage_store<KT, WSTEP>(st, smem, tid);
+        x_relayout();
+        __syncthreads();
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            NMF_STAMP(tk0);
+            const int par = (ch - c_begin) & 1;
+            const float *__restrict__ vb = smem + par * VBUF;
+            float *__restrict__ vn = smem + (par ^ 1) * VBUF;
+            // Branch-free body: past the last chunk the "next chunk" is the current one again (its image lands in the
+            // other LDS buffer and in registers nobody reads).
+            const int chn = (ch + 1 < c_end) ? ch + 1 : ch;
+            set_chunk(chn);
+            // ---- product 1: one dependent chain, operands through a ring of single ds_read_b32
+            const lds_float *b1 = (const lds_float *)vb + p1_off;
+            float ar[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) ar[i] = lds_ld(b1 + 2 * i * kLdv);
+            NMF_STAMP(tk1);
+            // S accumulates in VGPRs (inline asm, "v" constraint): the divide reads it without 16
+            // v_accvgpr_read, and hipcc stops parking an accumulator tile elsewhere to reuse its AGPRs.
+            // hipcc pads nothing around asm: the s_nop run below covers MFMA-result -> VALU-read.
+            f32x16 s;
+            constexpr int NLOAD = KT + 4;   // 4 X pieces first, then KT pieces of V, spread evenly over the chain
+#pragma unroll
+            for (int ss = 0; ss < N1; ++ss) {
+                if (ss == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(s) : "v"(ar[0]), "v"(ub[0]));
+                else         asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(s) : "v"(ar[ss % D]), "v"(ub[ss]));
+                if (ss + D < N1) ar[ss % D] = lds_ld(b1 + 2 * (ss + D) * kLdv);
+                constexpr int G = N1 / (NLOAD + 1);            // one load every G MFMAs
+                if (ss >= G && ss % G == 0 && ss / G - 1 < NLOAD) {
+                    const int j = ss / G - 1;
+                    if (j < 4) x_load_one(j); else stage_load_one(j - 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s));
+            NMF_STAMP(tk2);
+            // ---- first operands of product 2 (LDS, hidden) before the VALU block
+            const lds_float *b2 = (const lds_float *)vb + p2_off;
+            float a2[D];
+#pragma unroll
+            for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 32 * (e % KT) * kLdv + rho(e / KT));
+            // ---- quotient, all 16 rows in ONE block of VALU work (set_epsilon + vec_div, cuda/nmf.cu:128-131)
+            // (sched_barrier: instruction selection otherwise sinks each divide next to the MFMA row that uses
+            //  it, and every VALU<->MFMA switch costs ~13 cycles on top of the VALU issue time)
+            float z[16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = quotient<DIV>(xr[r], clamp_eps(s[r]));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- next chunk's X tile into the accumulator layout (LDS only)
+            x_relayout();
+            NMF_STAMP(tk3);
+            // ---- product 2: KT independent accumulators, no VALU inside
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const int e = r * KT + t;
+                    acc[t] = NMF_MFMA(a2[e % D], z[r], acc[t]);
+                    if (e + D < 16 * KT) a2[e % D] = lds_ld(b2 + 32 * ((e + D) % KT) * kLdv + rho((e + D) / KT));
+                    // the next chunk's LDS image: 4*KT single writes, one every 2nd step from step E/8 (a burst of them
+                    // saturates the ~75 B/clk LDS store path and delays the operand reads queued behind it)
+                    constexpr int E0 = (16 * KT) / 8;
+                    if (e >= E0 && (e - E0) % 2 == 0 && (e - E0) / 2 < 4 * KT) {
+                        stage_store_one(vn, (e - E0) / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            NMF_STAMP(tk4);
+            __syncthreads();
+            NMF_STAMP(tk5);
+            if (STAMP) { seg[0] += tk1 - tk0; seg[1] += tk2 - tk1; seg[2] += tk3 - tk2; seg[3] += tk4 - tk3; seg[4] += tk5 - tk4; }
+        }
+        if (STAMP && lane == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.partials) + ((size_t)blockIdx.x * 4 + wave) * 7;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) dbg[i] = seg[i];
+        }
+    }
+    if (!active) return;
+    fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
+}
+
+// Variants (NMF_FUSED_VARIANT): 3 = production (default); 1 = first chunk-serial kernel; 2 = software-pipelined
+// experiment.  NMF_FAST_DIVIDE=1 selects the refined-reciprocal quotient (<= 1 ulp) in variant 3.
 static int fused_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && e[0] == '2') ? 2 : 1; }
+    if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 3; }
+    return v;
+}
+static int fused_fast_divide() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NMF_FAST_DIVIDE"); v = (e && e[0] == '1') ? 1 : 0; }
     return v;
 }
 
@@ -509,31 +739,54 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
     const int nqblk = (Q + 127) / 128;
     const dim3 grid((unsigned)(nqblk * a.nsplit)), block(256);
     const bool partial = a.partial != 0;
-    const bool v1 = fused_variant() == 1;
-    const size_t lds = (size_t)(v1 ? 2 : 3) * KT * 32 * kLdv * sizeof(float);
-#define NMF_LAUNCH_FUSED(KERNEL, W_, P_)                                                                  \
+    int variant = fused_variant();
+    // v3 addresses the streamed factor and the X tile with 32-bit lane offsets
+    if (variant == 3 && ((size_t)a.Kp * (size_t)a.Mp >= ((size_t)1 << 31) || (size_t)40 * (size_t)a.Mp >= ((size_t)1 << 31))) variant = 1;
+    const size_t vbuf = (size_t)KT * 32 * kLdv * sizeof(float);
+    const size_t lds = variant == 1 ? 2 * vbuf : variant == 2 ? 3 * vbuf : 2 * vbuf + 4 * kXtFloats * sizeof(float);
+#define NMF_LAUNCH_FUSED(...)                                                                             \
     do {                                                                                                  \
         static bool attr_done = false;                                                                    \
         if (!attr_done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)KERNEL<KT, W_, P_>,                          \
+            hipError_t e = hipFuncSetAttribute((const void *)__VA_ARGS__,                                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             if (e != hipSuccess) return e;                                                                \
             attr_done = true;                                                                             \
         }                                                                                                 \
-        hipLaunchKernelGGL((KERNEL<KT, W_, P_>), grid, block, lds, stream, a);                            \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
-    if (v1) {
-        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, false, false);
-        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, false, true);
-        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1, true, false);
-        else NMF_LAUNCH_FUSED(fused_step_kernel_v1, true, true);
+    if (variant == 1) {
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, false, false>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, false, true>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, true, false>);
+        else NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, true, true>);
+    } else if (variant == 2) {
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, false, false>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, false, true>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, false>);
+        else NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, true>);
+    } else if (fused_fast_divide()) {
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, false, 1>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, true, 1>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, false, 1>);
+        else NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, true, 1>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel, false, false);
-        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel, false, true);
-        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel, true, false);
-        else NMF_LAUNCH_FUSED(fused_step_kernel, true, true);
+        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, false, 0>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, true, 0>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, false, 0>);
+        else NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, true, 0>);
     }
 #undef NMF_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
+// diagnostic: v3 H-step (KT = 8, in place, IEEE divide) with in-kernel stamps; a.partials receives 5 x uint64 per wave
+hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream) {
+    if (a.Kp != 256 || !a.partials) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.Np + 127) / 128)), block(256);
+    const size_t lds = (size_t)2 * 8 * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)fused_step_kernel_v3<8, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fused_step_kernel_v3<8, false, false, 0, true>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -576,6 +829,9 @@ __global__ __launch_bounds__(256, 1) void mfma_mix_probe_kernel(float *out, int 
     unsigned sx = 0;
     const unsigned laddr = (threadIdx.x & 255) * 4;
     const float *gp = out + 65536 + threadIdx.x;
+    const float *gp4 = out + 65536 + 4 * threadIdx.x;
+    const unsigned laddr4 = (threadIdx.x & 63) * 16;
+    f32x4 d4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
@@ -588,13 +844,15 @@ __global__ __launch_bounds__(256, 1) void mfma_mix_probe_kernel(float *out, int 
                 if (KIND == 3) asm volatile("global_load_dword %0, %1, off" : "=v"(d[v & 3]) : "v"(gp));
                 if (KIND == 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d[v & 3]) : "a"(acc[7][v & 3]));
                 if (KIND == 5) asm volatile("ds_write_b32 %0, %1" :: "v"(laddr), "v"(d[v & 3]));
+                if (KIND == 6) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d4[v & 3]) : "v"(gp4));
+                if (KIND == 7) asm volatile("ds_write_b128 %0, %1" :: "v"(laddr4), "v"(d4[v & 3]));
             }
-            if ((KIND == 1 || KIND == 3 || KIND == 5) && (i & 7) == 7) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+            if ((KIND == 1 || KIND == 3 || KIND == 5 || KIND == 6 || KIND == 7) && (i & 7) == 7) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-    float sum = d[0] + d[1] + d[2] + d[3] + (float)sx;
+    float sum = d[0] + d[1] + d[2] + d[3] + (float)sx + d4[0][0] + d4[1][1] + d4[2][2] + d4[3][3];
 #pragma unroll
     for (int t = 0; t < 8; ++t) sum += acc[t][0];
     out[blockIdx.x * 256 + threadIdx.x] = sum;
@@ -602,10 +860,61 @@ __global__ __launch_bounds__(256, 1) void mfma_mix_probe_kernel(float *out, int 
 hipError_t launch_mfma_valu_probe(int nv, int kind, float *out, int iters, hipStream_t stream) {
 #define NMF_MP2(NV_, K_) if (nv == NV_ && kind == K_) { hipLaunchKernelGGL((mfma_mix_probe_kernel<NV_, K_>), dim3(256), dim3(256), 0, stream, out, iters); return hipGetLastError(); }
 #define NMF_MP(K_) NMF_MP2(0, K_) NMF_MP2(1, K_) NMF_MP2(2, K_) NMF_MP2(4, K_)
-    NMF_MP(0) NMF_MP(1) NMF_MP(2) NMF_MP(3) NMF_MP(4) NMF_MP(5)
+    NMF_MP(0) NMF_MP(1) NMF_MP(2) NMF_MP(3) NMF_MP(4) NMF_MP(5) NMF_MP(6) NMF_MP(7)
 #undef NMF_MP
 #undef NMF_MP2
     return hipErrorInvalidValue;
+}
+
+// Micro-probe 2: two waves per SIMD (512-thread workgroup).  Waves 0-3 issue only f32 MFMAs, waves 4-7
+// only VALU (MODE 1), only LDS reads (MODE 2) or nothing (MODE 0).  Does the partner's work slow the MFMAs?
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_partner_probe_kernel(float *out, int iters) {
+    __shared__ float lds[1024];
+    lds[threadIdx.x & 1023] = 1.0f;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float sum = 0.f;
+    if (wave < 4) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        float a = (float)threadIdx.x, b = 1.0f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) acc[i & 3] = NMF_MFMA(a, b, acc[i & 3]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sum += acc[t][0];
+    } else if (MODE == 1) {
+        float d0 = 1.f, d1 = 2.f, d2 = 3.f, d3 = 4.f;
+        for (int it = 0; it < iters * 8; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d0)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d1));
+                asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d2)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d3));
+            }
+        }
+        sum = d0 + d1 + d2 + d3;
+    } else if (MODE == 2) {
+        const unsigned laddr = (threadIdx.x & 255) * 4;
+        float d0 = 0.f;
+        for (int it = 0; it < iters * 8; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(d0) : "v"(laddr));
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        }
+        sum = d0;
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = sum;
+}
+hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream) {
+    if (mode == 0) hipLaunchKernelGGL((mfma_partner_probe_kernel<0>), dim3(256), dim3(512), 0, stream, out, iters);
+    else if (mode == 1) hipLaunchKernelGGL((mfma_partner_probe_kernel<1>), dim3(256), dim3(512), 0, stream, out, iters);
+    else hipLaunchKernelGGL((mfma_partner_probe_kernel<2>), dim3(256), dim3(512), 0, stream, out, iters);
+    return hipGetLastError();
 }
 
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
