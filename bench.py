@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz
 # HBM bytes per fused_step launch at cfg3 from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
 # profiles/r01_pmc_summary.md).  bench.py cannot collect PMC itself; other shapes report null.
-PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.343e9, "W": 1.309e9}}
+PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.351e9, "W": 1.309e9}}
 
 
 def synth(seed, rows, cols):
@@ -199,7 +199,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.md); algorithmic 1.21e9",
-                         "kernel": "fused_step_kernel<KT=%d> (%s-step instantiation, the slower of the two)" % (-(-K // 32), "H" if ms_h >= ms_w else "W"),
+                         "kernel": "fused_step_kernel_v3<KT=%d> (%s-step instantiation, the slower of the two)" % (-(-K // 32), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
                          "measured": f"hipEvents around {reps} back-to-back launches on the solver stream, after the timed region"},
