@@ -189,6 +189,8 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
         NMFCHK(dev_alloc(&s->Z, mn));
         NMFCHK(dev_alloc(&s->WtZ, kn));
         NMFCHK(dev_alloc(&s->ZHt, mk));
+        s->nsplit_w = 16;                                  // split-K slabs for the Z*H' GEMM
+        NMFCHK(dev_alloc(&s->partials, (size_t)s->nsplit_w * mk));
         s->chk_groups = reduce_num_groups(mn);
     }
     HIPCHK(hipMalloc((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups));
@@ -361,7 +363,7 @@ static int enqueue_w_partial(nmf_solver *s) {
         HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
         HIPCHK(launch_set_epsilon(s->Z, mn, st));
         HIPCHK(launch_vec_div(s->X, s->Z, s->Z, mn, st));
-        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->psum, s->Mp, st));
+        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->psum, s->Mp, st, s->partials, (size_t)s->nsplit_w * mk));
     }
     return NMF_OK;
 }
@@ -408,7 +410,7 @@ static int enqueue_update_w(nmf_solver *s) {
     { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }   // nmf.cu:164-165
     {
         PieceScope p(s, NMF_T_W_STEP);
-        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->ZHt, s->Mp, st)); // nmf.cu:168
+        HIPCHK(launch_gemm(GEMM_NT, s->Mp, s->Kp, s->Np, s->Z, s->Mp, s->H, s->Kp, s->ZHt, s->Mp, st, s->partials, (size_t)s->nsplit_w * mk)); // nmf.cu:168
     }
     {
         PieceScope p(s, NMF_T_APPLY);
@@ -726,6 +728,19 @@ extern "C" int nmf_matrix_multiply_AtB(matrix a, matrix b, matrix c, void *strea
 extern "C" int nmf_matrix_multiply_ABt(matrix a, matrix b, matrix c, void *stream) {
     NMFCHK(need_dev(a, "matrix_multiply_ABt")); NMFCHK(need_dev(b, "matrix_multiply_ABt")); NMFCHK(need_dev(c, "matrix_multiply_ABt"));
     if (a.dim[1] != b.dim[1] || c.dim[0] != a.dim[0] || c.dim[1] != b.dim[0]) return shape_err("matrix_multiply_ABt");
+    // small output + long reduction: split K through a temporary slab workspace (this entry point synchronises then)
+    const size_t per = (size_t)c.dim[0] * c.dim[1];
+    const int tiles = ((c.dim[0] + 127) / 128) * ((c.dim[1] + 127) / 128);
+    if (tiles < 128 && a.dim[1] >= 4096) {
+        float *ws = nullptr;
+        const size_t nws = 16 * per;
+        HIPCHK(hipMalloc((void **)&ws, nws * sizeof(float)));
+        hipError_t e = launch_gemm(GEMM_NT, c.dim[0], c.dim[1], a.dim[1], a.mat_d, a.dim[0], b.mat_d, b.dim[0], c.mat_d, c.dim[0], (hipStream_t)stream, ws, nws);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(ws);
+        HIPCHK(e);
+        return NMF_OK;
+    }
     HIPCHK(launch_gemm(GEMM_NT, c.dim[0], c.dim[1], a.dim[1], a.mat_d, a.dim[0], b.mat_d, b.dim[0], c.mat_d, c.dim[0], (hipStream_t)stream));
     return NMF_OK;
 }

@@ -61,8 +61,9 @@ hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *p
 // ---------------------------------------------------------------- unfused operators
 enum GemmKind { GEMM_NN = 0, GEMM_TN = 1, GEMM_NT = 2 };
 // C(m x n, ldc) = op(A) * op(B) with reduction length k; fp32 MFMA, arbitrary sizes.
+// `workspace` (optional): enables split-K for small outputs with a long reduction (slabs summed in fixed order).
 hipError_t launch_gemm(GemmKind kind, int m, int n, int k, const float *A, long lda, const float *B, long ldb,
-                       float *C, long ldc, hipStream_t stream);
+                       float *C, long ldc, hipStream_t stream, float *workspace = nullptr, size_t workspace_floats = 0);
 hipError_t launch_set_epsilon(float *a, size_t n, hipStream_t stream);
 hipError_t launch_vec_div(const float *a, const float *b, float *c, size_t n, hipStream_t stream);
 hipError_t launch_vec_mul(const float *a, const float *b, float *c, size_t n, hipStream_t stream);

@@ -1198,8 +1198,13 @@ hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *p
 //   A(i,l) = A[i*sai + l*sal],  B(l,j) = B[l*sbl + j*sbj],  C(i,j) = C[i + j*ldc]
 constexpr int kGemmLd = 129;
 template <bool A_LCONTIG, bool B_LCONTIG>
-__global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, const float *__restrict__ A, long sai, long sal,
-                                                   const float *__restrict__ B, long sbl, long sbj, float *__restrict__ C, long ldc) {
+__global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k_total, const float *__restrict__ A, long sai, long sal,
+                                                   const float *__restrict__ B, long sbl, long sbj, float *__restrict__ C, long ldc,
+                                                   int k_per_split, size_t slab) {
+    // split-K: blockIdx.z owns reduction range [z*k_per_split, ...) and writes its own slab of C
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k = (k_begin + k_per_split < k_total) ? (k_begin + k_per_split) : k_total;   // exclusive end
+    C += (size_t)blockIdx.z * slab;
     __shared__ float As[16 * kGemmLd];
     __shared__ float Bs[16 * kGemmLd];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -1235,8 +1240,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, const fl
             Bs[lb * kGemmLd + jb] = rb[q];
         }
     };
-    fetch(0);
-    for (int l0 = 0; l0 < k; l0 += 16) {
+    fetch(k_begin);
+    for (int l0 = k_begin; l0 < k; l0 += 16) {
         commit();
         __syncthreads();
         if (l0 + 16 < k) fetch(l0 + 16);
@@ -1267,21 +1272,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(int m, int n, int k, const fl
 }
 
 hipError_t launch_gemm(GemmKind kind, int m, int n, int k, const float *A, long lda, const float *B, long ldb, float *C, long ldc,
-                       hipStream_t stream) {
+                       hipStream_t stream, float *workspace, size_t workspace_floats) {
     if (m <= 0 || n <= 0 || k <= 0) return hipErrorInvalidValue;
-    const dim3 grid((m + 127) / 128, (n + 127) / 128), block(256);
+    const int tiles = ((m + 127) / 128) * ((n + 127) / 128);
+    // small output, long reduction (Z*H' of the W-step): split K over workgroups into slabs, then sum them in order
+    int nsplit = 1;
+    if (workspace && tiles < 256 && ldc == m) {
+        nsplit = (512 + tiles - 1) / tiles;
+        const int max_by_k = k / 256 > 0 ? k / 256 : 1;
+        if (nsplit > max_by_k) nsplit = max_by_k;
+        const size_t per = (size_t)m * n;
+        if ((size_t)nsplit * per > workspace_floats) nsplit = (int)(workspace_floats / per);
+        if (nsplit < 2) nsplit = 1;
+    }
+    int kper = (k + nsplit - 1) / nsplit;
+    kper = (kper + 15) & ~15;
+    nsplit = (k + kper - 1) / kper;
+    const dim3 grid((m + 127) / 128, (n + 127) / 128, nsplit), block(256);
+    float *out = nsplit > 1 ? workspace : C;
+    const size_t slab = nsplit > 1 ? (size_t)m * n : 0;
+    const long ldo = nsplit > 1 ? (long)m : ldc;
     switch (kind) {
         case GEMM_NN:   // A(i,l) = A[i + l*lda]; B(l,j) = B[l + j*ldb]
-            hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, 1L, ldb, C, ldc);
+            hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, 1L, ldb, out, ldo, kper, slab);
             break;
         case GEMM_TN:   // A stored (k x m): A(i,l) = A[l + i*lda]
-            hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, m, n, k, A, lda, 1L, B, 1L, ldb, C, ldc);
+            hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, m, n, k, A, lda, 1L, B, 1L, ldb, out, ldo, kper, slab);
             break;
         case GEMM_NT:   // B stored (n x k): B(l,j) = B[j + l*ldb]
-            hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, ldb, 1L, C, ldc);
+            hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, m, n, k, A, 1L, lda, B, ldb, 1L, out, ldo, kper, slab);
             break;
     }
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || nsplit == 1) return e;
+    return launch_sum_partials(C, workspace, nsplit, (size_t)m * n, stream);
 }
 
 __global__ __launch_bounds__(256) void set_epsilon_kernel(float *__restrict__ a, size_t n) {

@@ -17,8 +17,13 @@ def _dev(ng, a):
     return ng.Matrix(a).to_device()
 
 
+def _tol64(k):
+    """fp32 fmaf-chain error against fp64 grows with the chain length (1e-6 up to K = 4096 on uniform data)"""
+    return 1e-6 if k <= 4096 else 3e-6
+
+
 GEMM_SHAPES = [(128, 128, 64), (1024, 4096, 64), (4096, 352, 128), (70, 45, 33), (1, 1, 1), (129, 257, 17),
-               (256, 96, 300)]
+               (256, 96, 300), (300, 100, 9000)]   # the last one takes the split-K path of A*B'
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -31,7 +36,7 @@ def test_matrix_multiply_nn(ng, oracle, m, n, k):
     want = oracle.sgemm("nn", A, B)
     assert oracle.relF(got, want) < 2e-6
     ref64 = A.astype(np.float64) @ B.astype(np.float64)
-    assert oracle.relF(got, ref64) < 1e-6
+    assert oracle.relF(got, ref64) < _tol64(k)
 
 
 def test_matrix_multiply_identity_asymmetric(ng):
@@ -58,7 +63,7 @@ def test_matrix_multiply_AtB(ng, oracle, m, n, k):
     ng.matrix_multiply_AtB(_dev(ng, A), _dev(ng, B), c)
     got = c.from_device().mat
     assert oracle.relF(got, oracle.sgemm("tn", A, B)) < 2e-6
-    assert oracle.relF(got, A.astype(np.float64).T @ B.astype(np.float64)) < 1e-6
+    assert oracle.relF(got, A.astype(np.float64).T @ B.astype(np.float64)) < _tol64(k)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -69,7 +74,7 @@ def test_matrix_multiply_ABt(ng, oracle, m, n, k):
     ng.matrix_multiply_ABt(_dev(ng, A), _dev(ng, B), c)
     got = c.from_device().mat
     assert oracle.relF(got, oracle.sgemm("nt", A, B)) < 2e-6
-    assert oracle.relF(got, A.astype(np.float64) @ B.astype(np.float64).T) < 1e-6
+    assert oracle.relF(got, A.astype(np.float64) @ B.astype(np.float64).T) < _tol64(k)
 
 
 def test_gemm_shape_errors(ng):
