@@ -242,3 +242,88 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     s.close()
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 2, 25)
     print("cfg3 K_par=2 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
+
+
+def test_cli_reference_workflow(ng, oracle, tmp_path):
+    """The reference's workflow (matrix_export.py -> ./nmf -> Wout/Hout, cuda/nmf.cu:30-51) with the
+    shipped CLI: same .bin files in, same .bin files out, checked by tolerance instead of md5."""
+    import subprocess
+    from conftest import ROOT
+    M, N, K = 512, 350, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    for name, A in (("X", X), ("W", W), ("H", H)):
+        oracle.write_bin(str(tmp_path / f"{name}.bin"), A)
+    cli = os.path.join(ROOT, "nmf-gpu_amd", "nmf")
+    r = subprocess.run([cli, "--X", str(tmp_path / "X.bin"), "--W", str(tmp_path / "W.bin"), "--H", str(tmp_path / "H.bin"),
+                        "--Wout", str(tmp_path / "Wout.bin"), "--Hout", str(tmp_path / "Hout.bin"), "--iters", "40", "--timers"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "40 iterations" in r.stdout and "write" in r.stdout
+    Wo, Ho = oracle.read_bin(str(tmp_path / "Wout.bin")), oracle.read_bin(str(tmp_path / "Hout.bin"))
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 40, 25)
+    _cmp(oracle, Wo, Ho, Wr, Hr, 1e-5)
+    # a missing input is an error with a message, not a crash (the reference never checks fopen, cuda/nmf.cu:196)
+    r = subprocess.run([cli, "--X", str(tmp_path / "nope.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def test_update_div_from_device_buffers(ng, oracle):
+    """matrix.mat_d as the source/sink (README: 'data can also just be stored ... using the matrix struct')"""
+    M, N, K = 200, 300, 40
+    X, W, H = oracle.gen_problem(M, N, K, seed=8)
+    Wm, Hm, Xm = ng.Matrix(W).to_device(), ng.Matrix(H).to_device(), ng.Matrix(X).to_device()
+    ng.update_div(Wm, Hm, Xm, 0.0, 15, None, 0)
+    Wh, Hh = Wm.mat.copy(), Hm.mat.copy()
+    Wm.from_device(); Hm.from_device()             # the device mirrors were updated too
+    assert np.array_equal(Wm.mat, Wh) and np.array_equal(Hm.mat, Hh)
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 15, 25)
+    _cmp(oracle, Wh, Hh, Wr, Hr, 1e-5)
+
+
+def test_fast_divide_option_same_parity(ng, oracle):
+    """NMF_FAST_DIVIDE=1 (reciprocal refined to <= 1 ulp) must satisfy the same parity gate as the IEEE default."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, oracle, nmf_gpu_amd as ng\n"
+        "X, W, H = oracle.gen_problem(1024, 4096, 64, seed=0)\n"
+        "Wm, Hm = ng.Matrix(W), ng.Matrix(H)\n"
+        "ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 200, None, 0)\n"
+        "Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)\n"
+        "print('RELF', oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NMF_FAST_DIVIDE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    eW, eH = (float(v) for v in r.stdout.split("RELF")[1].split())
+    print("fast divide cfg2 relF =", eW, eH)
+    assert eW < TOL and eH < TOL
+
+
+def test_full_size_properties_cfg4_shard_shape(ng):
+    """Maximum single-GPU size of the BASELINE configs: M=4096 N=262144 R=256 (config 4 unsharded: X is 4 GiB,
+    past every 32-bit element-offset limit of the reference, cuda/matrix.cu:61,77,136).  Too big for the CPU
+    oracle in a test, so only the size-independent invariants of the KL update are checked (see the cfg3 test)."""
+    M, N, K = 4096, 262144, 256
+    rng = np.random.default_rng(1)
+    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    kl0, _ = s.check()
+    s.update_h()
+    W1, H1 = s.download()
+    colsum_wh = W1.astype(np.float64).sum(axis=0) @ H1.astype(np.float64)
+    xs = X.sum(axis=0, dtype=np.float64)
+    assert np.allclose(colsum_wh, xs, rtol=2e-5)
+    # the last columns are computed by the last workgroups: catches any 32-bit wrap in the addressing
+    assert np.allclose(colsum_wh[-64:], xs[-64:], rtol=2e-5) and np.allclose(colsum_wh[N // 2 - 32:N // 2 + 32], xs[N // 2 - 32:N // 2 + 32], rtol=2e-5)
+    s.update_w()
+    W2, H2 = s.download()
+    rowsum_wh = W2.astype(np.float64) @ H2.astype(np.float64).sum(axis=1)
+    assert np.allclose(rowsum_wh, X.sum(axis=1, dtype=np.float64), rtol=2e-5)
+    kl1, _ = s.check()
+    s.iterate(2)
+    kl2, _ = s.check()
+    assert kl0 > kl1 > kl2 > 0 and np.isfinite(H2).all() and np.isfinite(W2).all()
+    s.close()
