@@ -16,6 +16,9 @@
 extern "C" {
 #endif
 
+/* the shared library is built with -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
+
 /* ---------------------------------------------------------------------------------------
  * The reference's matrix struct (README.md:31-36: "column-major float array ... proper
  * assignment of the dim values"; upstream layout {mat, mat_d, dim[2]}).  `mat` is the
@@ -194,6 +197,15 @@ int  nmf_solver_path(const nmf_solver *s);
 void *nmf_solver_stream(nmf_solver *s);
 
 /* ---------------------------------------------------------------------------------------
+ * Multi-restart NMF (paper section 3.2: "multiple random initializations and choose the best"): X is
+ * uploaded once, each (W[i], H[i]) pair runs the same update_div loop, the pair with the lowest final KL
+ * divergence wins.  All pairs are updated in place; *best receives the winner's index, kl[i] (may be NULL)
+ * each pair's final KL.
+ * ------------------------------------------------------------------------------------- */
+int  update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts,
+                         int *best, double *kl);
+
+/* ---------------------------------------------------------------------------------------
  * RCCL communicator for N-sharded runs (new: the reference is single-GPU).  One process
  * per GPU; rank 0 creates the id, the launcher broadcasts its 128 bytes (e.g. with
  * torch.distributed), every rank calls nmf_comm_init_rank.
@@ -208,6 +220,8 @@ void nmf_comm_destroy(nmf_comm *c);
 int  nmf_device_count(void);
 int  nmf_device_name(int device, char *buf, int buflen);
 const char *nmf_version(void);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = [
-    "EPS", "Matrix", "Solver", "NmfError", "update_div", "update_div_ex", "read_matrix", "write_matrix",
+    "EPS", "Matrix", "Solver", "NmfError", "update_div", "update_div_ex", "update_div_restarts", "read_matrix", "write_matrix",
     "matrix_multiply", "matrix_multiply_AtB", "matrix_multiply_ABt", "element_multiply", "element_divide",
     "row_divide", "col_divide", "set_epsilon", "sum_cols", "sum_rows", "kl_divergence", "diff_norm",
     "Comm", "device_count", "device_name", "lib", "LIB_PATH", "PATH_AUTO", "PATH_FUSED", "PATH_UNFUSED",
@@ -61,6 +61,7 @@ _f32p = C.POINTER(C.c_float)
 _SIGS = [
     ("update_div", None, [_matrix, _matrix, _matrix, C.c_float, C.c_int, C.POINTER(C.c_double), C.c_int]),
     ("update_div_ex", C.c_int, [_matrix, _matrix, _matrix, C.POINTER(_opts), C.POINTER(_result)]),
+    ("update_div_restarts", C.c_int, [C.POINTER(_matrix), C.POINTER(_matrix), C.c_int, _matrix, C.POINTER(_opts), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("nmf_default_opts", None, [C.POINTER(_opts)]),
     ("nmf_status_string", C.c_char_p, [C.c_int]),
     ("nmf_last_error", C.c_char_p, []),
@@ -263,6 +264,24 @@ def update_div_ex(W, H, X, **opts) -> dict:
     r = _result()
     _chk(lib().update_div_ex(W._c, H._c, X._c, C.byref(o), C.byref(r)))
     return _result_dict(r)
+
+
+def update_div_restarts(Ws, Hs, X, **opts):
+    """Paper section 3.2: run every (W, H) initialisation, keep X resident; returns (best_index, [kl...]).
+    All pairs are updated in place."""
+    Ws = [_as_matrix(w) for w in Ws]
+    Hs = [_as_matrix(h) for h in Hs]
+    X = _as_matrix(X)
+    n = len(Ws)
+    if n == 0 or len(Hs) != n:
+        raise NmfError(1, "need the same positive number of W and H initialisations")
+    wa = (_matrix * n)(*[w._c for w in Ws])
+    ha = (_matrix * n)(*[h._c for h in Hs])
+    o = _make_opts(**opts)
+    best = C.c_int(-1)
+    kl = (C.c_double * n)()
+    _chk(lib().update_div_restarts(wa, ha, n, X._c, C.byref(o), C.byref(best), kl))
+    return best.value, [kl[i] for i in range(n)]
 
 
 # ------------------------------------------------------------------------------ operators

@@ -684,6 +684,42 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
     return st;
 }
 
+// Multi-restart (paper section 3.2): X resident once, every (W,H) pair through the same loop, best final KL wins.
+extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts_in, int *best, double *kl) {
+    if (!W || !H || n_restarts < 1 || (!X.mat && !X.mat_d)) { set_err("update_div_restarts: bad arguments"); return NMF_ERR_ARG; }
+    nmf_opts o;
+    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    const int M = X.dim[0], N = X.dim[1], K = W[0].dim[1];
+    for (int i = 0; i < n_restarts; ++i) {
+        if (!W[i].mat || !H[i].mat) { set_err("update_div_restarts: pair %d has no host data", i); return NMF_ERR_ARG; }
+        if (W[i].dim[0] != M || W[i].dim[1] != K || H[i].dim[0] != K || H[i].dim[1] != N) {
+            set_err("update_div_restarts: pair %d: dimensions do not agree", i);
+            return NMF_ERR_SHAPE;
+        }
+    }
+    nmf_solver *s = nullptr;
+    NMFCHK(nmf_solver_create(&s, M, N, K, &o));
+    int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
+    int best_i = -1;
+    double best_kl = 0.0;
+    for (int i = 0; st == NMF_OK && i < n_restarts; ++i) {
+        st = nmf_solver_upload(s, W[i].mat, H[i].mat, nullptr);
+        nmf_result res;
+        memset(&res, 0, sizeof res);
+        if (st == NMF_OK) st = solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, &res, false);
+        double v = 0.0;
+        if (st == NMF_OK) st = nmf_solver_check(s, &v, nullptr);
+        if (st == NMF_OK) st = nmf_solver_download(s, W[i].mat, H[i].mat);
+        if (st == NMF_OK) {
+            if (kl) kl[i] = v;
+            if (best_i < 0 || v < best_kl) { best_i = i; best_kl = v; }
+        }
+    }
+    nmf_solver_destroy(s);
+    if (st == NMF_OK && best) *best = best_i;
+    return st;
+}
+
 // README.md:40-46.  void + exit on error like the reference (error-check.hpp:12-17).
 extern "C" void update_div(matrix W, matrix H, matrix X, float CONVERGE_THRESH, int max_iter, double t[10], int verbose) {
     nmf_opts o;

@@ -509,6 +509,24 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel(FusedArgs a) {
 constexpr int kXtLd = 36;                       // X patch row stride in floats (16-B aligned, b128 conflict-free)
 constexpr int kXtFloats = 32 * kXtLd;           // per wave
 
+// v3 assigns the two k indices of product-1 step s to k = s (lanes 0-31) and k = s + 16*KT (lanes 32-63), so that a lane's
+// B operands are contiguous in k: the H-step loads them as 16-B pieces (4x fewer lane-strided loads than k = 2s + h).
+template <int KT, bool WSTEP>
+__device__ __forceinline__ void load_u_split(float (&ub)[KT * 16], const float *__restrict__ U, long ldu, int q0, int c, int h) {
+    constexpr int N1 = KT * 16;
+    if (!WSTEP) {
+        const float *__restrict__ col = U + (size_t)(N1 * h) + (size_t)(q0 + c) * ldu;
+#pragma unroll
+        for (int s4 = 0; s4 < N1 / 4; ++s4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 4 * s4);
+            ub[4 * s4] = v[0]; ub[4 * s4 + 1] = v[1]; ub[4 * s4 + 2] = v[2]; ub[4 * s4 + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + c) + (size_t)(s + N1 * h) * ldu];
+    }
+}
+
 // LDS pointer with its address space spelled out: a volatile load through a generic pointer is not
 // rewritten by address-space inference and would become flat_load + 64-bit address arithmetic.
 typedef __attribute__((address_space(3))) float lds_float;
@@ -559,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
     const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
 
     float ub[KT * 16];
-    load_u<KT, WSTEP>(ub, U, ldu, q0, c, h);
+    load_u_split<KT, WSTEP>(ub, U, ldu, q0, c, h);
 
     f32x16 acc[KT];
 #pragma unroll
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
         const float *__restrict__ xt_r = WSTEP ? xt + 4 * h * kXtLd + c       // + rho(r) rows
                                                : xt + c * kXtLd + 4 * h;      // + 8g floats
         // LDS operand bases (floats) inside a V buffer
-        const int p1_off = h * kLdv + c;          // product 1: + 2*ss*kLdv
+        const int p1_off = N1 * h * kLdv + c;     // product 1, step ss: k = ss + N1*h  ->  + ss*kLdv
         const int p2_off = c * kLdv + 4 * h;      // product 2: + 32*t*kLdv + rho(r)
 
         f32x4 st[KT];
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             float ar[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) ar[i] = lds_ld(b1 + 2 * i * kLdv);
+            for (int i = 0; i < D; ++i) ar[i] = lds_ld(b1 + i * kLdv);
             NMF_STAMP(tk1);
             // S accumulates in VGPRs (inline asm, "v" constraint): the divide reads it without 16
             // v_accvgpr_read, and hipcc stops parking an accumulator tile elsewhere to reuse its AGPRs.
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
             for (int ss = 0; ss < N1; ++ss) {
                 if (ss == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(s) : "v"(ar[0]), "v"(ub[0]));
                 else         asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(s) : "v"(ar[ss % D]), "v"(ub[ss]));
-                if (ss + D < N1) ar[ss % D] = lds_ld(b1 + 2 * (ss + D) * kLdv);
+                if (ss + D < N1) ar[ss % D] = lds_ld(b1 + (ss + D) * kLdv);
                 constexpr int G = N1 / (NLOAD + 1);            // one load every G MFMAs
                 if (ss >= G && ss % G == 0 && ss / G - 1 < NLOAD) {
                     const int j = ss / G - 1;

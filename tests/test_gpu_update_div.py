@@ -327,3 +327,21 @@ def test_full_size_properties_cfg4_shard_shape(ng):
     kl2, _ = s.check()
     assert kl0 > kl1 > kl2 > 0 and np.isfinite(H2).all() and np.isfinite(W2).all()
     s.close()
+
+
+def test_multi_restart_picks_lowest_kl(ng, oracle):
+    """paper section 3.2 / SURVEY 8(f4): several initialisations against one resident X, best final KL wins"""
+    M, N, K, R = 128, 200, 16, 4
+    X, _, _ = oracle.gen_problem(M, N, K, seed=0)
+    rng = np.random.default_rng(5)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    Wm, Hm = [ng.Matrix(w) for w in Ws], [ng.Matrix(h) for h in Hs]
+    best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=30)
+    ref = []
+    for w, h in zip(Ws, Hs):
+        wr, hr, _, _ = oracle.update_div(w, h, X, 0.0, 30, 25)
+        ref.append(oracle.kl_div(oracle.clamp(X), np.maximum(oracle.sgemm("nn", wr, hr), oracle.EPS)))
+    assert np.allclose(kls, ref, rtol=1e-4) and best == int(np.argmin(ref))
+    wr, hr, _, _ = oracle.update_div(Ws[best], Hs[best], X, 0.0, 30, 25)
+    _cmp(oracle, Wm[best].mat, Hm[best].mat, wr, hr, 1e-5)
