@@ -48,7 +48,8 @@ class _matrix(C.Structure):
 class _opts(C.Structure):
     _fields_ = [("converge_thresh", C.c_float), ("max_iter", C.c_int), ("iter_check", C.c_int),
                 ("verbose", C.c_int), ("path", C.c_int), ("use_graph", C.c_int), ("device", C.c_int),
-                ("stream", C.c_void_p), ("comm", C.c_void_p), ("nsplit_h", C.c_int), ("nsplit_w", C.c_int)]
+                ("stream", C.c_void_p), ("comm", C.c_void_p), ("nsplit_h", C.c_int), ("nsplit_w", C.c_int),
+                ("fast_divide", C.c_int)]
 
 
 class _result(C.Structure):
@@ -360,10 +361,11 @@ class Solver:
 
     def __init__(self, M: int, N: int, K: int, *, path: int = PATH_AUTO, use_graph: bool = True,
                  device: int = -1, stream: Optional[int] = None, comm: Optional[Comm] = None,
-                 nsplit_h: int = 0, nsplit_w: int = 0):
+                 nsplit_h: int = 0, nsplit_w: int = 0, fast_divide: bool = False):
         self.M, self.N, self.K = M, N, K
         o = _make_opts(path=path, use_graph=int(use_graph), device=device, stream=stream,
-                       comm=(comm._h.value if comm is not None else None), nsplit_h=nsplit_h, nsplit_w=nsplit_w)
+                       comm=(comm._h.value if comm is not None else None), nsplit_h=nsplit_h, nsplit_w=nsplit_w,
+                       fast_divide=int(fast_divide))
         self._h = C.c_void_p()
         self._comm = comm
         _chk(lib().nmf_solver_create(C.byref(self._h), M, N, K, C.byref(o)))

@@ -81,6 +81,7 @@ extern "C" void nmf_default_opts(nmf_opts *o) {
     o->comm = nullptr;
     o->nsplit_h = 0;
     o->nsplit_w = 0;
+    o->fast_divide = 0;
 }
 
 static double now_s() {
@@ -94,6 +95,7 @@ struct nmf_solver {
     int path = NMF_PATH_FUSED;
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
+    int fast_divide = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
@@ -159,6 +161,7 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     }
     s->path = path;
     s->use_graph = o.use_graph;
+    s->fast_divide = o.fast_divide;
     s->comm = (nmf_comm *)o.comm;
     if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
@@ -303,7 +306,7 @@ static FusedArgs fused_args(nmf_solver *s) {
     FusedArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.norm = nullptr;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide;
     return a;
 }
 
@@ -597,6 +600,15 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
+                if (which == 4000) {   // IEEE vs refined-reciprocal quotient: mismatch census over ~1e9 operand pairs
+                    HIPCHK(hipMemsetAsync(s->chk_part, 0, 16, st));
+                    HIPCHK(launch_divide_compare((unsigned long long *)s->chk_part, 12345u + (unsigned)i, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    unsigned long long c2[2];
+                    HIPCHK(hipMemcpy(c2, s->chk_part, 16, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "divide census: %llu of %llu pairs differ, max distance %llu ulp\n", c2[0], 4096ull * 256 * 1000, c2[1]);
+                    break;
+                }
                 if (which == 3000) {   // in-kernel stamps of the v3 H-step: prints the per-chunk segment cycles
                     fa.nsplit = 1; fa.partial = 0; fa.U_out = s->H; fa.norm = s->normW; fa.partials = s->partials;
                     HIPCHK(launch_fused_stamp(fa, st));

@@ -29,11 +29,13 @@ struct FusedArgs {
     int Mp, Np, Kp;
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
+    int fast_divide;          // 1: refined-reciprocal quotient instead of IEEE division (v3 kernel only)
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe
 hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream);   // micro-probe 2
 hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream);   // diagnostic stamps
+hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipStream_t stream);   // diagnostic
 hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream);   // timing probes (v1 kernel + ablation mask)
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,

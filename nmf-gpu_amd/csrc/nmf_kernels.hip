@@ -783,7 +783,7 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
         else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, false, true>);
         else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, false>);
         else NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, true>);
-    } else if (fused_fast_divide()) {
+    } else if (fused_fast_divide() || a.fast_divide) {
         if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, false, 1>);
         else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, true, 1>);
         else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, false, 1>);
@@ -932,6 +932,37 @@ hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_
     if (mode == 0) hipLaunchKernelGGL((mfma_partner_probe_kernel<0>), dim3(256), dim3(512), 0, stream, out, iters);
     else if (mode == 1) hipLaunchKernelGGL((mfma_partner_probe_kernel<1>), dim3(256), dim3(512), 0, stream, out, iters);
     else hipLaunchKernelGGL((mfma_partner_probe_kernel<2>), dim3(256), dim3(512), 0, stream, out, iters);
+    return hipGetLastError();
+}
+
+// Diagnostic: how often does quotient<1> (refined reciprocal) differ from the IEEE quotient on operands of the
+// kind the kernel sees (x in [EPS, 2), y = clamped dot products in [EPS, 300))?  counts[0] = mismatches, counts[1] = max ulp distance.
+__global__ __launch_bounds__(256) void divide_compare_kernel(unsigned long long *counts, unsigned seed, int per_thread) {
+    unsigned st = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    unsigned long long bad = 0, maxulp = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        st = st * 1664525u + 1013904223u; const unsigned a = st;
+        st = st * 1664525u + 1013904223u; const unsigned b = st;
+        st = st * 1664525u + 1013904223u; const unsigned m = st >> 28;
+        float x = (float)(a >> 8) * (1.0f / 16777216.0f) * 2.0f;
+        float y = (float)(b >> 8) * (1.0f / 16777216.0f);
+        // spread y over many binades: 2^-52 .. 2^8
+        y = ldexpf(y + 0.5f, (int)(m * 4) - 52 + (int)((st >> 20) & 3));
+        x = clamp_eps(x); y = clamp_eps(y);
+        if (m == 0) x = ldexpf(x, -40);   // small numerators too
+        const float q0 = quotient<0>(x, y), q1 = quotient<1>(x, y);
+        if (q0 != q1) {
+            ++bad;
+            const long long d = (long long)__float_as_int(q0) - (long long)__float_as_int(q1);
+            const unsigned long long ad = d < 0 ? -d : d;
+            if (ad > maxulp) maxulp = ad;
+        }
+    }
+    atomicAdd(&counts[0], bad);
+    atomicMax(&counts[1], maxulp);
+}
+hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipStream_t stream) {
+    hipLaunchKernelGGL(divide_compare_kernel, dim3(4096), dim3(256), 0, stream, counts, seed, 1000);
     return hipGetLastError();
 }
 
