@@ -86,6 +86,25 @@ def test_shape_errors_before_any_gpu_work(ng):
     assert e.value.status == 2
 
 
+def test_empty_matrices_are_rejected(ng):
+    """zero-sized / NULL inputs -> NMF_ERR_ARG, never a launch (the reference would cudaMalloc(0) and launch empty grids)"""
+    import ctypes as C
+    from nmf_gpu_amd.api import _matrix, _opts, _result
+    buf = (C.c_float * 4)()
+    def m(rows, cols, data=True):
+        x = _matrix(); x.mat = C.cast(buf, C.POINTER(C.c_float)) if data else None; x.mat_d = None
+        x.dim[0], x.dim[1] = rows, cols
+        return x
+    L = ng.lib()
+    assert L.update_div_ex(m(0, 2), m(2, 2), m(0, 2), None, None) == 1
+    assert L.update_div_ex(m(2, 2), m(2, 0), m(2, 0), None, None) == 1
+    assert L.update_div_ex(m(2, 2, data=False), m(2, 2), m(2, 2), None, None) == 1
+    h = C.c_void_p()
+    assert L.nmf_solver_create(C.byref(h), 0, 4, 4, None) == 1 and L.nmf_solver_create(C.byref(h), 4, 4, -1, None) == 1
+    with pytest.raises(ValueError):
+        ng.Matrix(rows=0, cols=3)
+
+
 def test_fails_loudly_without_gpu_or_library(ng, monkeypatch):
     if ng.device_count() > 0:
         pytest.skip("GPU present")

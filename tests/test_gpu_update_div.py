@@ -341,3 +341,17 @@ def test_multi_restart_picks_lowest_kl(ng, oracle):
     assert np.allclose(kls, ref, rtol=1e-4) and best == int(np.argmin(ref))
     wr, hr, _, _ = oracle.update_div(Ws[best], Hs[best], X, 0.0, 30, 25)
     _cmp(oracle, Wm[best].mat, Hm[best].mat, wr, hr, 1e-5)
+
+
+def test_k_above_fused_limit_takes_unfused_path(ng, oracle):
+    """R > 256 (BASELINE config 5 has R = 512): PATH_AUTO must fall back to the operator path and stay in parity."""
+    M, N, K = 256, 384, 320
+    X, W, H = oracle.gen_problem(M, N, K, seed=12)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=20)
+    assert r["path_used"] == ng.PATH_UNFUSED
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 20, 25)
+    _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr, 1e-5)
+    with pytest.raises(ng.NmfError) as e:
+        ng.Solver(M, N, K, path=ng.PATH_FUSED)
+    assert e.value.status == 7
