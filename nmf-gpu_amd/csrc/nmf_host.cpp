@@ -127,10 +127,10 @@ static int dev_alloc(float **p, size_t count) {
     return NMF_OK;
 }
 
-static int pick_nsplit(int q_extent, int p_extent) {
-    // workgroups per split-less launch = ceil(Q/128); aim for >= 512 workgroups (2 per CU),
+static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
+    // workgroups per split-less launch = ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU),
     // keep >= 2 chunks of 32 per split.
-    const int nq = (q_extent + 127) / 128;
+    const int nq = (q_extent + q_per_group - 1) / q_per_group;
     if (nq >= 256) return 1;
     int ns = (512 + nq - 1) / nq;
     const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
@@ -150,12 +150,10 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     s->M = M; s->N = N; s->K = K;
     s->Mp = pad32(M); s->Np = pad32(N);
     int path = o.path;
-    if (path == NMF_PATH_AUTO) path = (pad32(K) <= 32 * kMaxFusedKT) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
+    if (path == NMF_PATH_AUTO) path = fused_pad_k(K) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED) {
-        if (pad32(K) > 32 * kMaxFusedKT) { delete s; set_err("fused path supports K <= %d", 32 * kMaxFusedKT); return NMF_ERR_UNSUPPORTED; }
-        int kt = pad32(K) / 32, ktp = 1;
-        while (ktp < kt) ktp <<= 1;     // instantiated tile counts: 1, 2, 4, 8
-        s->Kp = ktp * 32;
+        if (!fused_pad_k(K)) { delete s; set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
+        s->Kp = fused_pad_k(K);         // 32/64/128/256 (32x32x2 kernel) or 320/384/448/512 (16x16x4 kernel)
     } else {
         s->Kp = pad32(K);
     }
@@ -179,15 +177,16 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     NMFCHK(dev_alloc(&s->psum_owned, mk + (size_t)s->Kp));
     s->psum = s->psum_owned;
     if (path == NMF_PATH_FUSED) {
-        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp);
-        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np);
+        const int qg = fused_cols_per_group(s->Kp);
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
         size_t pc = 0;
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
         if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
         NMFCHK(dev_alloc(&s->partials, pc));
-        s->chk_groups = check_num_groups(s->Np);
+        s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else {
         NMFCHK(dev_alloc(&s->Z, mn));
         NMFCHK(dev_alloc(&s->WtZ, kn));

@@ -10,7 +10,7 @@ namespace nmf {
 
 constexpr float kEps = (float)(2.2204E-16);   // cuda/matrix.cu:10
 constexpr int kPad = 32;                      // device buffers are padded to multiples of 32 (cf. PAD_MULT, cuda/matrix.cuh:7)
-constexpr int kMaxFusedKT = 8;                // fused path: K_padded <= 256
+constexpr int kMaxFusedK = 512;                // fused path: K <= 512 (32x32x2 kernel up to 256, 16x16x4 kernel above)
 
 inline int pad32(int v) { return (v + 31) & ~31; }
 
@@ -47,7 +47,9 @@ hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp
 
 // KL(X || max(W*H,EPS)), sum|X-WH|, sum|X| over the valid (non-padded, X > 0) entries:
 // per-workgroup partial triples into `part` (3 doubles per workgroup), then launch_check_final.
-int        check_num_groups(int Np);
+int        check_num_groups(int Np, int Kp);
+int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
+int        fused_pad_k(int K);             // K padded to an instantiated kernel size, 0 if the fused path cannot take it
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,
                         double *part, hipStream_t stream);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);

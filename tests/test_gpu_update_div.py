@@ -343,14 +343,33 @@ def test_multi_restart_picks_lowest_kl(ng, oracle):
     _cmp(oracle, Wm[best].mat, Hm[best].mat, wr, hr, 1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 384, 320), (200, 130, 300), (96, 520, 512), (320, 64, 400)])
+def test_k_between_256_and_512_fused_16x16x4_kernel(ng, oracle, M, N, K):
+    """256 < R <= 512 (BASELINE config 5 has R = 512) runs the 16-column-per-wave kernel; parity as for R <= 256,
+    including its KL check, split reductions and ragged sizes."""
+    X, W, H = oracle.gen_problem(M, N, K, seed=12)
+    for nsplit in (0, 2):
+        s = ng.Solver(M, N, K, nsplit_h=nsplit, nsplit_w=nsplit)
+        assert s.path == ng.PATH_FUSED
+        s.upload(W, H, X)
+        kl0, _ = s.check()
+        s.iterate(10)
+        kl1, rl1 = s.check()
+        Wg, Hg = s.download()
+        s.close()
+        Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 10, 10)
+        _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5)
+        assert abs(kl0 - klr[0]) / klr[0] < 1e-5 and abs(kl1 - klr[1]) / klr[1] < 1e-5 and 0 < rl1 < 1
+
+
 def test_k_above_fused_limit_takes_unfused_path(ng, oracle):
-    """R > 256 (BASELINE config 5 has R = 512): PATH_AUTO must fall back to the operator path and stay in parity."""
-    M, N, K = 256, 384, 320
+    """R > 512: PATH_AUTO must fall back to the operator path and stay in parity."""
+    M, N, K = 128, 192, 600
     X, W, H = oracle.gen_problem(M, N, K, seed=12)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)
-    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=20)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=10)
     assert r["path_used"] == ng.PATH_UNFUSED
-    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 20, 25)
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 10, 25)
     _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr, 1e-5)
     with pytest.raises(ng.NmfError) as e:
         ng.Solver(M, N, K, path=ng.PATH_FUSED)
