@@ -599,10 +599,11 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
         const unsigned xstep = 4u * 8u * (unsigned)ldx;                              // bytes per i (32-bit on purpose)
         const char *__restrict__ xbase = reinterpret_cast<const char *>(WSTEP ? a.X + (size_t)q0 : a.X + (size_t)q0 * (size_t)ldx);
         const size_t xchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldx : (size_t)32);
-        float *__restrict__ xt = smem + 2 * VBUF + wave * kXtFloats;          // this wave's X patch
-        float *__restrict__ xt_w = xt + (lane >> 3) * kXtLd + 4 * (lane & 7); // write position (+ 8i rows)
-        const float *__restrict__ xt_r = WSTEP ? xt + 4 * h * kXtLd + c       // + rho(r) rows
-                                               : xt + c * kXtLd + 4 * h;      // + 8g floats
+        // (no __restrict__ here: the patch is written and read back through these pointers within one wave)
+        float *xt = smem + 2 * VBUF + wave * kXtFloats;                       // this wave's X patch
+        float *xt_w = xt + (lane >> 3) * kXtLd + 4 * (lane & 7);              // write position (+ 8i rows)
+        const float *xt_r = WSTEP ? xt + 4 * h * kXtLd + c                    // + rho(r) rows
+                                  : xt + c * kXtLd + 4 * h;                   // + 8g floats
         // LDS operand bases (floats) inside a V buffer
         const int p1_off = N1 * h * kLdv + c;     // product 1, step ss: k = ss + N1*h  ->  + ss*kLdv
         const int p2_off = c * kLdv + 4 * h;      // product 2: + 32*t*kLdv + rho(r)
@@ -1043,9 +1044,9 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_k16(FusedArgs a, dou
         const unsigned xstep = WSTEP ? 4u * 16u * (unsigned)ldx : 4u * 8u * (unsigned)ldx;
         const char *__restrict__ xbase = reinterpret_cast<const char *>(WSTEP ? a.X + (size_t)q0 : a.X + (size_t)q0 * (size_t)ldx);
         const size_t xchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldx : (size_t)32);
-        float *__restrict__ xt = smem + 2 * VBUF + wave * kXt16Floats;
-        float *__restrict__ xt_w = WSTEP ? xt + (lane >> 2) * 20 + 4 * (lane & 3) : xt + (lane >> 3) * kXtLd + 4 * (lane & 7);
-        const float *__restrict__ xt_r = WSTEP ? xt + 4 * kq * 20 + j : xt + j * kXtLd + 4 * kq;
+        float *xt = smem + 2 * VBUF + wave * kXt16Floats;   // no __restrict__: written and read back within the wave
+        float *xt_w = WSTEP ? xt + (lane >> 2) * 20 + 4 * (lane & 3) : xt + (lane >> 3) * kXtLd + 4 * (lane & 7);
+        const float *xt_r = WSTEP ? xt + 4 * kq * 20 + j : xt + j * kXtLd + 4 * kq;
         const int p1_off = 16 * kq * kLdv + j;     // + (64 (s>>4) + (s&15)) * kLdv + 16 T
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
