@@ -79,6 +79,9 @@ def main():
                     help="N>1: all-reduce through torch.distributed (default) or in-library RCCL inside the hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--strong-total-N", type=int, default=0,
+                    help="strong scaling instead of the default weak scaling: total column count split over the ranks "
+                         "(BASELINE config 4: --strong-total-N 262144)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="rehearsal only: gloo lets several ranks share one GPU (with --same-device)")
@@ -111,7 +114,10 @@ def main():
             dist.init_process_group(backend="gloo")
 
     M, Nloc, K = args.M, args.N, args.K
-    Ntot = Nloc * world
+    if args.strong_total_N:
+        shards = ng.column_shards(args.strong_total_N, world)
+        Nloc = shards[rank][1] - shards[rank][0]
+    Ntot = args.strong_total_N if args.strong_total_N else Nloc * world
     flops_per_iter = 8.0 * M * Ntot * K
 
     # synthetic inputs (data: "synthetic"), already resident in HBM before the timed region
@@ -186,7 +192,7 @@ def main():
             "iterations_per_s": its,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong_total_N else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
                                    + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {args.comm})" if world > 1 else " (BASELINE config 3)"),
