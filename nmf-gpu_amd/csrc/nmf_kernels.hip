@@ -107,6 +107,8 @@ __device__ __forceinline__ void load_u(float (&ub)[KT * 16], const float *__rest
     }
 }
 
+__device__ __forceinline__ void block_reduce3(double v0, double v1, double v2, double *out3, int tid);   // defined with the check kernels below
+
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 #define NMF_SG_VALU 0x002
 #define NMF_SG_MFMA 0x008
@@ -553,8 +555,10 @@ __device__ __forceinline__ float quotient(float x, float y) {
             __builtin_amdgcn_sched_barrier(0);                                                             \
         }                                                                                                  \
     } while (0)
-template <int KT, bool WSTEP, bool PARTIAL, int DIV, bool STAMP = false>
-__global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
+// CHECK = true: the KL / rel-L1 convergence check (product 1 only; reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640):
+// one triple {KL, sum|x-y|, sum|x|} per workgroup into chk_part.
+template <int KT, bool WSTEP, bool PARTIAL, int DIV, bool STAMP = false, bool CHECK = false>
+__global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a, double *__restrict__ chk_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VBUF = KT * 32 * kLdv;
     constexpr int N1 = KT * 16;
@@ -585,6 +589,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    double kl = 0.0, dabs = 0.0, xabs = 0.0;
     if (c_begin < c_end) {
         // ---- per-thread constants: 32-bit lane offsets (floats) from wave-uniform chunk bases
         // V staging: H-step rows k = (tid>>3) + 32q, 16-B piece i4 = tid&7; W-step column i = (tid>>3)&31, piece k4 = 8q + (tid&7)
@@ -691,6 +696,24 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s));
             NMF_STAMP(tk2);
+            if (CHECK) {
+                float fkl = 0.f, fd = 0.f, fx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = xr[r], y = clamp_eps(s[r]);
+                    if (x > 0.f) {   // padding is exactly 0; real inputs are >= EPS (cuda/nmf.cu:211)
+                        fkl += x * (logf(x) - logf(y)) - x + y;   // cuda/matrix.cu:592
+                        fd += fabsf(x - y);                       // cuda/matrix.cu:517
+                        fx += fabsf(x);                           // cuda/matrix.cu:518
+                    }
+                }
+                kl += (double)fkl; dabs += (double)fd; xabs += (double)fx;
+                x_relayout();
+#pragma unroll
+                for (int w = 0; w < 4 * KT; ++w) stage_store_one(vn, w);
+                __syncthreads();
+                continue;
+            }
             // ---- first operands of product 2 (LDS, hidden) before the VALU block
             const lds_float *b2 = (const lds_float *)vb + p2_off;
             float a2[D];
@@ -735,6 +758,11 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a) {
             for (int i = 0; i < 7; ++i) dbg[i] = seg[i];
         }
     }
+    if (CHECK) {
+        if (!active) { kl = 0.0; dabs = 0.0; xabs = 0.0; }
+        block_reduce3(kl, dabs, xabs, chk_part + 3 * (size_t)blockIdx.x, tid);
+        return;
+    }
     if (!active) return;
     fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
 }
@@ -774,6 +802,17 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
         }                                                                                                 \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
+#define NMF_LAUNCH_FUSED3(...)                                                                            \
+    do {                                                                                                  \
+        static bool attr_done = false;                                                                    \
+        if (!attr_done) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void *)__VA_ARGS__,                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            if (e != hipSuccess) return e;                                                                \
+            attr_done = true;                                                                             \
+        }                                                                                                 \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
+    } while (0)
     if (variant == 1) {
         if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, false, false>);
         else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, false, true>);
@@ -785,17 +824,18 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
         else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, false>);
         else NMF_LAUNCH_FUSED(fused_step_kernel<KT, true, true>);
     } else if (fused_fast_divide() || a.fast_divide) {
-        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, false, 1>);
-        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, true, 1>);
-        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, false, 1>);
-        else NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, true, 1>);
+        if (!wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, false, 1>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, true, 1>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, false, 1>);
+        else NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, true, 1>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, false, 0>);
-        else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, false, true, 0>);
-        else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, false, 0>);
-        else NMF_LAUNCH_FUSED(fused_step_kernel_v3<KT, true, true, 0>);
+        if (!wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, false, 0>);
+        else if (!wstep && partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, true, 0>);
+        else if (wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, false, 0>);
+        else NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, true, 0>);
     }
 #undef NMF_LAUNCH_FUSED
+#undef NMF_LAUNCH_FUSED3
     return hipGetLastError();
 }
 
@@ -805,7 +845,7 @@ hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.Np + 127) / 128)), block(256);
     const size_t lds = (size_t)2 * 8 * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
     (void)hipFuncSetAttribute((const void *)fused_step_kernel_v3<8, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fused_step_kernel_v3<8, false, false, 0, true>), grid, block, lds, stream, a);
+    hipLaunchKernelGGL((fused_step_kernel_v3<8, false, false, 0, true>), grid, block, lds, stream, a, (double *)nullptr);
     return hipGetLastError();
 }
 
@@ -966,8 +1006,6 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
     hipLaunchKernelGGL(divide_compare_kernel, dim3(4096), dim3(256), 0, stream, counts, seed, 1000);
     return hipGetLastError();
 }
-
-__device__ __forceinline__ void block_reduce3(double v0, double v1, double v2, double *out3, int tid);   // defined with the check kernels below
 
 // =====================================================================================
 // Fused half-step for 256 < K <= 512 (BASELINE config 5 has R = 512): same algorithm as v3 on
@@ -1414,6 +1452,21 @@ int check_num_groups(int Np, int Kp) { return (Np + fused_cols_per_group(Kp) - 1
 
 template <int KT>
 static hipError_t launch_check_kt(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+    // the production half-step kernel in CHECK mode (product 1 + KL terms); NMF_FUSED_VARIANT=1 keeps the first-generation check_kernel
+    if (fused_variant() != 1 && (size_t)Kp * (size_t)Mp < ((size_t)1 << 31)) {
+        FusedArgs a;
+        a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
+        a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
+        const size_t lds3 = (size_t)2 * KT * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
+        static bool attr3_done = false;
+        if (!attr3_done) {
+            hipError_t e = hipFuncSetAttribute((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) return e;
+            attr3_done = true;
+        }
+        hipLaunchKernelGGL((fused_step_kernel_v3<KT, false, false, 0, false, true>), dim3(check_num_groups(Np, Kp)), dim3(256), lds3, stream, a, part);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
