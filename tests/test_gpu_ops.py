@@ -23,7 +23,8 @@ def _tol64(k):
 
 
 GEMM_SHAPES = [(128, 128, 64), (1024, 4096, 64), (4096, 352, 128), (70, 45, 33), (1, 1, 1), (129, 257, 17),
-               (256, 96, 300), (300, 100, 9000)]   # the last one takes the split-K path of A*B'
+               (256, 96, 300), (300, 100, 9000),   # takes the split-K path of A*B'
+               (256, 384, 144), (128, 128, 16), (384, 256, 4112)]   # tile-aligned: the 16-B-load fast path (+ split-K)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
