@@ -112,9 +112,9 @@ struct nmf_solver {
     float *staging = nullptr;      // unpadded upload/download staging (max of the three matrices)
     size_t staging_count = 0;
     // graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_ready = false;
+    hipGraph_t graph = nullptr, graph8 = nullptr;       // one iteration / kGraphBatch iterations
+    hipGraphExec_t graph_exec = nullptr, graph8_exec = nullptr;
+    bool graph_ready = false, graph8_ready = false;
     // piece timing (eager, hipEvent pairs)
     bool timing = false;
     struct Ev { int which; hipEvent_t a, b; };
@@ -213,6 +213,8 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     (void)hipStreamSynchronize(s->stream);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
+    if (s->graph8) (void)hipGraphDestroy(s->graph8);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     float *bufs[] = {s->W, s->H, s->X, s->normW, s->normH, s->rowpart, s->partials, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
     for (float *b : bufs) if (b) (void)hipFree(b);
@@ -449,21 +451,36 @@ extern "C" int nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size
     return NMF_OK;
 }
 
-// cuda/nmf.cu:100-115: capture one iteration, replay it
-static int ensure_graph(nmf_solver *s) {
-    if (s->graph_ready) return NMF_OK;
+// cuda/nmf.cu:100-115: capture one iteration, replay it.  A second graph holds kGraphBatch iterations: a graph
+// replay costs ~10-16 us of host/launch time, which is most of a small problem's iteration (cfg2: ~70 us).
+constexpr int kGraphBatch = 8;
+static int capture_graph(nmf_solver *s, int iterations, hipGraph_t *graph, hipGraphExec_t *exec) {
     const double t0 = now_s();
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int st = enqueue_update_h(s);
-    if (st == NMF_OK) st = enqueue_update_w(s);
+    int st = NMF_OK;
+    for (int i = 0; i < iterations && st == NMF_OK; ++i) {
+        st = enqueue_update_h(s);
+        if (st == NMF_OK) st = enqueue_update_w(s);
+    }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(s->stream, &g);
     if (st != NMF_OK) { if (g) (void)hipGraphDestroy(g); return st; }
     if (e != hipSuccess) { set_err("hipStreamEndCapture: %s", hipGetErrorString(e)); return NMF_ERR_HIP; }
-    s->graph = g;
-    HIPCHK(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
-    s->graph_ready = true;
+    *graph = g;
+    HIPCHK(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
     s->t_setup += now_s() - t0;
+    return NMF_OK;
+}
+static int ensure_graph(nmf_solver *s) {
+    if (s->graph_ready) return NMF_OK;
+    NMFCHK(capture_graph(s, 1, &s->graph, &s->graph_exec));
+    s->graph_ready = true;
+    return NMF_OK;
+}
+static int ensure_graph8(nmf_solver *s) {
+    if (s->graph8_ready) return NMF_OK;
+    NMFCHK(capture_graph(s, kGraphBatch, &s->graph8, &s->graph8_exec));
+    s->graph8_ready = true;
     return NMF_OK;
 }
 
@@ -473,7 +490,10 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
     if (s->use_graph && !s->timing) {
         int st = ensure_graph(s);
         if (st == NMF_OK) {
-            for (int i = 0; i < iters; ++i) HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));
+            int left = iters;
+            if (left >= kGraphBatch && ensure_graph8(s) == NMF_OK)
+                for (; left >= kGraphBatch; left -= kGraphBatch) HIPCHK(hipGraphLaunch(s->graph8_exec, s->stream));
+            for (; left > 0; --left) HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));
             return NMF_OK;
         }
         // capture unavailable (e.g. a collective that cannot be captured): fall back to eager launches
