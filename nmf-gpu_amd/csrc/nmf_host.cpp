@@ -140,19 +140,31 @@ static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
     return ns;
 }
 
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o);
+
 extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nmf_opts *opts_in) {
     if (!out || M <= 0 || N <= 0 || K <= 0) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
     nmf_opts o;
     if (opts_in) o = *opts_in; else nmf_default_opts(&o);
-    const double t0 = now_s();
     if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
     nmf_solver *s = new nmf_solver();
+    const int st = solver_init(s, M, N, K, o);
+    if (st != NMF_OK) {   // release whatever was allocated before the failure
+        nmf_solver_destroy(s);
+        return st;
+    }
+    *out = s;
+    return NMF_OK;
+}
+
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
+    const double t0 = now_s();
     s->M = M; s->N = N; s->K = K;
     s->Mp = pad32(M); s->Np = pad32(N);
     int path = o.path;
     if (path == NMF_PATH_AUTO) path = fused_pad_k(K) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED) {
-        if (!fused_pad_k(K)) { delete s; set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
+        if (!fused_pad_k(K)) { set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
         s->Kp = fused_pad_k(K);         // 32/64/128/256 (32x32x2 kernel) or 320/384/448/512 (16x16x4 kernel)
     } else {
         s->Kp = pad32(K);
@@ -204,13 +216,12 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     NMFCHK(dev_alloc(&s->staging, s->staging_count));
     HIPCHK(hipStreamSynchronize(s->stream));
     s->t_setup = now_s() - t0;
-    *out = s;
     return NMF_OK;
 }
 
 extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (!s) return;
-    (void)hipStreamSynchronize(s->stream);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
     if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);

@@ -15,8 +15,27 @@
 #include "nmf_kernels.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace nmf {
+
+// Kernels that need more than 64 KiB of dynamic LDS must opt in once per (kernel, device).
+static hipError_t ensure_dynamic_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
+
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -793,23 +812,17 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
     const size_t lds = variant == 1 ? 2 * vbuf : variant == 2 ? 3 * vbuf : 2 * vbuf + 4 * kXtFloats * sizeof(float);
 #define NMF_LAUNCH_FUSED(...)                                                                             \
     do {                                                                                                  \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)__VA_ARGS__,                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        {                                                                                                 \
+            hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
             if (e != hipSuccess) return e;                                                                \
-            attr_done = true;                                                                             \
         }                                                                                                 \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
 #define NMF_LAUNCH_FUSED3(...)                                                                            \
     do {                                                                                                  \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)__VA_ARGS__,                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        {                                                                                                 \
+            hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
             if (e != hipSuccess) return e;                                                                \
-            attr_done = true;                                                                             \
         }                                                                                                 \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
@@ -1266,12 +1279,9 @@ static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t s
     const bool fast = fused_fast_divide() || a.fast_divide;
 #define NMF_LAUNCH_K16(...)                                                                               \
     do {                                                                                                  \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)__VA_ARGS__,                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        {                                                                                                 \
+            hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
             if (e != hipSuccess) return e;                                                                \
-            attr_done = true;                                                                             \
         }                                                                                                 \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
@@ -1296,11 +1306,9 @@ static hipError_t launch_check_k16(const float *W, const float *H, const float *
     a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
     a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)fused_step_kernel_k16<NB, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true>, lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
     return hipGetLastError();
@@ -1458,21 +1466,17 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
         a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
         a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
         const size_t lds3 = (size_t)2 * KT * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
-        static bool attr3_done = false;
-        if (!attr3_done) {
-            hipError_t e = hipFuncSetAttribute((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        {
+            hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, lds3);
             if (e != hipSuccess) return e;
-            attr3_done = true;
         }
         hipLaunchKernelGGL((fused_step_kernel_v3<KT, false, false, 0, false, true>), dim3(check_num_groups(Np, Kp)), dim3(256), lds3, stream, a, part);
         return hipGetLastError();
     }
     const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)check_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = ensure_dynamic_lds((const void *)check_kernel<KT>, lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((check_kernel<KT>), dim3(check_num_groups(Np, Kp)), dim3(256), lds, stream, W, H, X, Mp, Np, Kp, part);
     return hipGetLastError();
