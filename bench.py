@@ -174,11 +174,19 @@ def main():
         dist.all_reduce(kk)
         kl0, kl1 = float(kk[0]), float(kk[1])
 
-    # dominant kernel: fused_step (H- and W-step instantiations, 4*M*Nloc*K flop per launch each),
-    # timed with hipEvents on the solver's own stream right after the timed region
-    reps = max(3, min(args.steps, 20))
-    ms_h = s.time_piece(ng.api.T_H_STEP, reps)
-    ms_w = s.time_piece(ng.api.T_W_STEP, reps)
+    # dominant kernel: the fused half-step (H- and W-step instantiations, 4*M*Nloc*K flop per launch each).
+    # Its launch duration is measured live with hipEvent pairs around every launch, on the stream it is launched
+    # on, over a second pass of the same `steps` iterations (launched eagerly: events cannot sit inside a graph
+    # replay); rocprofv3 --kernel-trace of this command gives the same averages (profiles/).
+    if shard is None and s.path == ng.PATH_FUSED:
+        tp = s.iterate_timed(args.steps)
+        ms_h, ms_w = tp["h_step"] / args.steps * 1e3, tp["w_step"] / args.steps * 1e3
+        how = f"hipEvent pair around each of {args.steps} launches per kernel, eager pass of the same {args.steps} iterations after the timed region"
+    else:
+        reps = max(3, min(args.steps, 20))
+        ms_h = s.time_piece(ng.api.T_H_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
+        ms_w = s.time_piece(ng.api.T_W_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
+        how = f"hipEvents around {reps} back-to-back launches on the solver stream, after the timed region"
     ms_k = max(ms_h, ms_w)
     k_flops = 4.0 * M * Nloc * K
     achieved = k_flops / (ms_k * 1e-3) / 1e12
@@ -205,10 +213,10 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.md); algorithmic 1.21e9",
-                         "kernel": "fused_step_kernel_v3<KT=%d> (%s-step instantiation, the slower of the two)" % (-(-K // 32), "H" if ms_h >= ms_w else "W"),
+                         "kernel": "%s (%s-step instantiation, the slower of the two)" % ("fused_step_kernel_v3<KT=%d>" % (-(-K // 32)) if K <= 256 else "fused_step_kernel_k16<NB=%d>" % (-(-K // 64)), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
-                         "measured": f"hipEvents around {reps} back-to-back launches on the solver stream, after the timed region"},
+                         "measured": how},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, Ntot, K, args.cpu_budget)

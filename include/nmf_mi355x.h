@@ -171,6 +171,9 @@ int  nmf_solver_download(nmf_solver *s, float *W, float *H);
 /* enqueue `iters` iterations (H half-step then W half-step each, cuda/nmf.cu:108-109) on the
  * solver's stream; does not synchronise. */
 int  nmf_solver_iterate(nmf_solver *s, int iters);
+/* `iters` iterations launched eagerly with a hipEvent pair around every piece (the README's t[10], README.md:53):
+ * adds the device seconds of each piece to t[NMF_T_H_STEP .. NMF_T_ALLREDUCE]; synchronises. */
+int  nmf_solver_iterate_timed(nmf_solver *s, int iters, double t[10]);
 /* the two half-steps separately (cuda/nmf.cu:118-146 / 148-176) */
 int  nmf_solver_update_h(nmf_solver *s);
 int  nmf_solver_update_w(nmf_solver *s);

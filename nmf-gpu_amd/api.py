@@ -91,6 +91,7 @@ _SIGS = [
     ("nmf_solver_upload_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nmf_solver_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nmf_solver_iterate", C.c_int, [C.c_void_p, C.c_int]),
+    ("nmf_solver_iterate_timed", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("nmf_solver_update_h", C.c_int, [C.c_void_p]),
     ("nmf_solver_update_w", C.c_int, [C.c_void_p]),
     ("nmf_solver_check", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -410,6 +411,12 @@ class Solver:
 
     def iterate(self, iters: int = 1):
         _chk(lib().nmf_solver_iterate(self._h, iters))
+
+    def iterate_timed(self, iters: int = 1) -> dict:
+        """eager iterations with hipEvents around every piece; returns device seconds per piece name"""
+        t = (C.c_double * 10)()
+        _chk(lib().nmf_solver_iterate_timed(self._h, iters, t))
+        return {T_NAMES[i]: float(t[i]) for i in range(10)}
 
     def update_h(self):
         _chk(lib().nmf_solver_update_h(self._h))

@@ -519,6 +519,20 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
     return NMF_OK;
 }
 
+extern "C" int nmf_solver_iterate_timed(nmf_solver *s, int iters, double t[10]) {
+    if (!s || iters < 0 || !t) return NMF_ERR_ARG;
+    if (s->external_reduce) { set_err("solver is in external-reduce mode"); return NMF_ERR_UNSUPPORTED; }
+    s->timing = true;
+    int st = NMF_OK;
+    for (int i = 0; i < iters && st == NMF_OK; ++i) {
+        st = enqueue_update_h(s);
+        if (st == NMF_OK) st = enqueue_update_w(s);
+    }
+    const int st2 = collect_timing(s, t);
+    s->timing = false;
+    return st != NMF_OK ? st : st2;
+}
+
 // KL / rel-L1 of the current state (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640)
 extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) {
     if (!s || !sums) return NMF_ERR_ARG;
