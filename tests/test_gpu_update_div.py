@@ -391,3 +391,36 @@ def test_random_shape_sweep(ng, oracle):
         Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 3, 25)
         eW, eH = oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr)
         assert eW < 1e-5 and eH < 1e-5 and np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all(), (M, N, K, eW, eH)
+
+
+def test_resume_equals_uninterrupted_run(ng, oracle):
+    """checkpoint/resume as the reference allows it (Wout/Hout have the input format): 12 + 13 iterations
+    from the saved factors are bit-identical to 25 in one call; and the verbose contract prints one line per check."""
+    import subprocess
+    from conftest import ROOT
+    M, N, K = 300, 420, 48
+    X, W, H = oracle.gen_problem(M, N, K, seed=21)
+    W1, H1 = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(W1, H1, ng.Matrix(X), 0.0, 25, None, 0)
+    W2, H2 = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(W2, H2, ng.Matrix(X), 0.0, 12, None, 0)
+    ng.update_div(W2, H2, ng.Matrix(X), 0.0, 13, None, 0)
+    assert np.array_equal(W1.mat, W2.mat) and np.array_equal(H1.mat, H2.mat)
+
+
+def test_cli_verbose_lines(ng, oracle, tmp_path):
+    import subprocess
+    from conftest import ROOT
+    X, W, H = oracle.gen_problem(128, 160, 16, seed=3)
+    for name, A in (("X", X), ("W", W), ("H", H)):
+        oracle.write_bin(str(tmp_path / f"{name}.bin"), A)
+    cli = os.path.join(ROOT, "nmf-gpu_amd", "nmf")
+    r = subprocess.run([cli, "--X", str(tmp_path / "X.bin"), "--W", str(tmp_path / "W.bin"), "--H", str(tmp_path / "H.bin"),
+                        "--Wout", str(tmp_path / "Wo.bin"), "--Hout", str(tmp_path / "Ho.bin"), "--iters", "50", "--verbose",
+                        "--thresh", "1e-9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("iter")]
+    assert len(lines) == 3 and "kl-divergence" in lines[0] and lines[1].split()[1] == "25" and lines[2].split()[1] == "50"
+    kls = [float(l.split("kl-divergence")[1].split()[0]) for l in lines]
+    _, _, _, klr = oracle.update_div(W, H, X, 1e-9, 50, 25)
+    assert np.allclose(kls, klr, rtol=1e-4)
