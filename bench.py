@@ -138,7 +138,7 @@ def main():
         # half-step protocol + torch.distributed all-reduce of the (M*K + K)-float partial buffer
         shard = ng.GpuShard(M, Nloc, K, device=local_rank)
         s = shard.solver
-        loop = ng.ShardedLoop(shard, lambda t: dist.all_reduce(t), None)
+        loop = ng.ShardedLoop(shard, shard.allreduce_sum, shard.allreduce_scalars)
     else:
         s = ng.Solver(M, Nloc, K, use_graph=not args.no_graph, device=local_rank, comm=comm)
     s.upload(W, H, X)

@@ -92,18 +92,23 @@ class ShardedLoop:
 
 
 class GpuShard:
-    """Backend over the HIP solver.  The partial buffer is a torch tensor so that
-    torch.distributed (backend "nccl" = RCCL over xGMI) can all-reduce it in place; the solver
-    runs on torch's current stream so the collective is ordered after w_partial()."""
+    """Backend over the HIP solver.  The partial buffer is a torch tensor so that torch.distributed (backend
+    "nccl" = RCCL over xGMI) can all-reduce it in place.  Solver and collective share one dedicated torch stream:
+    torch orders a collective against the *current* stream, and the default stream's raw handle is NULL, which
+    the solver would read as "create your own stream" -- so never the default stream here."""
 
     def __init__(self, M: int, N_local: int, K: int, device: int = 0, **solver_kw):
         import torch
         from .api import Solver
         self.torch = torch
-        stream = torch.cuda.current_stream(device).cuda_stream
-        self.solver = Solver(M, N_local, K, device=device, stream=stream, use_graph=False, **solver_kw)
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0
+        self.solver = Solver(M, N_local, K, device=device, stream=self.stream.cuda_stream, use_graph=False, **solver_kw)
         _, cnt = self.solver.partial_buffer()
-        self.buf = torch.zeros(cnt, dtype=torch.float32, device=f"cuda:{device}")
+        with torch.cuda.stream(self.stream):
+            self.buf = torch.zeros(cnt, dtype=torch.float32, device=f"cuda:{device}")
+        self.stream.synchronize()
         self.solver.set_partial_buffer(self.buf.data_ptr(), cnt)
 
     def upload(self, W, H_local, X_local):
@@ -119,11 +124,27 @@ class GpuShard:
     def w_apply(self):
         self.solver.w_apply()
 
+    def allreduce_sum(self, t):
+        """sum all-reduce of `t` over the default process group, ordered on this shard's stream"""
+        import torch.distributed as dist
+        with self.torch.cuda.stream(self.stream):
+            dist.all_reduce(t)
+
+    def allreduce_scalars(self, values):
+        import torch.distributed as dist
+        with self.torch.cuda.stream(self.stream):
+            t = self.torch.tensor(values, dtype=self.torch.float64, device=f"cuda:{self.device}")
+            dist.all_reduce(t)
+            return t.tolist()
+
     def check_local(self):
         return self.solver.check_sums()
 
     def download(self):
         return self.solver.download()
+
+    def sync(self):
+        self.solver.sync()
 
     def close(self):
         self.solver.close()
