@@ -213,7 +213,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.md); algorithmic 1.21e9",
-                         "kernel": "%s (%s-step instantiation, the slower of the two)" % ("fused_step_kernel_v3<KT=%d>" % (-(-K // 32)) if K <= 256 else "fused_step_kernel_k16<NB=%d>" % (-(-K // 64)), "H" if ms_h >= ms_w else "W"),
+                         "kernel": "%s (%s-step instantiation, the slower of the two)" % ("fused_step_kernel_v3<KT=1>" if K <= 32 else "fused_step_kernel_k16<NB=%d>" % (-(-K // 64)), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
                          "measured": how},

@@ -119,12 +119,20 @@ def declared_symbols():
 
 
 _lib = None
+_loaded_before_torch = False
 
 
 def lib():
-    """Load libnmf_mi355x.so; raises if it has not been built (no fallback)."""
-    global _lib
+    """Load libnmf_mi355x.so; raises if it has not been built (no fallback).
+
+    PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If torch is imported first, this
+    library's HIP symbols bind to that same runtime (one runtime per process: streams and pointers interoperate);
+    if this library is loaded first and torch later, the process ends up with two HIP runtimes.  Code that shares
+    streams with torch (GpuShard, bench.py for N > 1) therefore imports torch before the first call in here."""
+    global _lib, _loaded_before_torch
     if _lib is None:
+        import sys
+        _loaded_before_torch = "torch" not in sys.modules
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP library first "

@@ -163,9 +163,9 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
     s->Mp = pad32(M); s->Np = pad32(N);
     int path = o.path;
     // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
-    const bool k16_too_tall = fused_pad_k(K) > 256 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << 31);
+    const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << 31);
     if (path == NMF_PATH_AUTO) path = (fused_pad_k(K) && !k16_too_tall) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
-    if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path for K > 256 supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
+    if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
         if (!fused_pad_k(K)) { set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
         s->Kp = fused_pad_k(K);         // 32/64/128/256 (32x32x2 kernel) or 320/384/448/512 (16x16x4 kernel)

@@ -786,11 +786,12 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a, doub
     fused_epilogue<KT, WSTEP, PARTIAL>(a, acc, split, q0, c, h, ldu);
 }
 
-// Variants (NMF_FUSED_VARIANT): 3 = production (default); 1 = first chunk-serial kernel; 2 = software-pipelined
-// experiment.  NMF_FAST_DIVIDE=1 selects the refined-reciprocal quotient (<= 1 ulp) in variant 3.
+// Variants (NMF_FUSED_VARIANT), for K <= 256: unset = production choice (16-column kernel at two workgroups per CU for
+// K = 64/128/256, v3 for K = 32); 3 = v3 (32-column kernel) everywhere; 1 = first chunk-serial kernel; 2 = software-
+// pipelined experiment.  NMF_FAST_DIVIDE=1 selects the refined-reciprocal quotient (<= 1 ulp) in variant 3.
 static int fused_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 3; }
+    if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 0; }   // 0 = automatic choice
     return v;
 }
 static int fused_fast_divide() {
@@ -806,6 +807,7 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
     const dim3 grid((unsigned)(nqblk * a.nsplit)), block(256);
     const bool partial = a.partial != 0;
     int variant = fused_variant();
+    if (variant == 0) variant = 3;
     // v3 addresses the streamed factor and the X tile with 32-bit lane offsets
     if (variant == 3 && ((size_t)a.Kp * (size_t)a.Mp >= ((size_t)1 << 31) || (size_t)40 * (size_t)a.Mp >= ((size_t)1 << 31))) variant = 1;
     const size_t vbuf = (size_t)KT * 32 * kLdv * sizeof(float);
@@ -1037,8 +1039,8 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
 #define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int kXt16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
 
-template <int NB, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false>
-__global__ __launch_bounds__(256, 1) void fused_step_kernel_k16(FusedArgs a, double *__restrict__ chk_part) {
+template <int NB, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, double *__restrict__ chk_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 64 * NB;
     constexpr int VBUF = K * kLdv;
@@ -1270,7 +1272,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_k16(FusedArgs a, dou
     }
 }
 
-template <int NB>
+template <int NB, int OCC>
 static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) {
     const int Q = wstep ? a.Mp : a.Np;
     const dim3 grid((unsigned)(((Q + 63) / 64) * a.nsplit)), block(256);
@@ -1279,64 +1281,67 @@ static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t s
     const bool fast = fused_fast_divide() || a.fast_divide;
 #define NMF_LAUNCH_K16(...)                                                                               \
     do {                                                                                                  \
-        {                                                                                                 \
-            hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
-            if (e != hipSuccess) return e;                                                                \
-        }                                                                                                 \
+        hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
+        if (e != hipSuccess) return e;                                                                    \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
     if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 1>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 1>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 1>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 1>);
+        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 1, false, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 1, false, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 1, false, OCC>);
+        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 1, false, OCC>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 0>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 0>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 0>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 0>);
+        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 0, false, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 0, false, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 0, false, OCC>);
+        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 0, false, OCC>);
     }
 #undef NMF_LAUNCH_K16
     return hipGetLastError();
 }
 
-template <int NB>
+template <int NB, int OCC>
 static hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
     FusedArgs a;
     a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
     a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
-    {
-        hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true>, lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
+    hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
     return hipGetLastError();
 }
+
+// which kernel family serves a padded K: the 16-column kernel for K = 64/128/256 (two workgroups per CU) and for
+// 256 < K <= 512 (one), v3 for K = 32 or when NMF_FUSED_VARIANT asks for it
+static bool use_k16(int Kp) { return Kp > 256 || (Kp >= 64 && fused_variant() == 0); }
 
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
     if ((a.Mp | a.Np | a.Kp) & 31) return hipErrorInvalidValue;
     if (a.nsplit < 1 || (a.nsplit > 1 && !a.partial)) return hipErrorInvalidValue;
-    if (a.Kp <= 256) {
-        switch (a.Kp / 32) {
-            case 1: return launch_fused_kt<1>(a, wstep, stream);
-            case 2: return launch_fused_kt<2>(a, wstep, stream);
-            case 4: return launch_fused_kt<4>(a, wstep, stream);
-            case 8: return launch_fused_kt<8>(a, wstep, stream);
+    if (use_k16(a.Kp)) {
+        if (a.Kp % 64) return hipErrorInvalidValue;
+        switch (a.Kp / 64) {
+            case 1: return launch_fused_k16<1, 2>(a, wstep, stream);
+            case 2: return launch_fused_k16<2, 2>(a, wstep, stream);
+            case 4: return launch_fused_k16<4, 2>(a, wstep, stream);
+            case 5: return launch_fused_k16<5, 1>(a, wstep, stream);
+            case 6: return launch_fused_k16<6, 1>(a, wstep, stream);
+            case 7: return launch_fused_k16<7, 1>(a, wstep, stream);
+            case 8: return launch_fused_k16<8, 1>(a, wstep, stream);
             default: return hipErrorInvalidValue;
         }
     }
-    if (a.Kp % 64) return hipErrorInvalidValue;
-    switch (a.Kp / 64) {   // 256 < K <= 512: 16-column-per-wave kernel
-        case 5: return launch_fused_k16<5>(a, wstep, stream);
-        case 6: return launch_fused_k16<6>(a, wstep, stream);
-        case 7: return launch_fused_k16<7>(a, wstep, stream);
-        case 8: return launch_fused_k16<8>(a, wstep, stream);
+    switch (a.Kp / 32) {
+        case 1: return launch_fused_kt<1>(a, wstep, stream);
+        case 2: return launch_fused_kt<2>(a, wstep, stream);
+        case 4: return launch_fused_kt<4>(a, wstep, stream);
+        case 8: return launch_fused_kt<8>(a, wstep, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-int fused_cols_per_group(int Kp) { return Kp <= 256 ? 128 : 64; }
+int fused_cols_per_group(int Kp) { return use_k16(Kp) ? 64 : 128; }
 int fused_pad_k(int K) {   // padded K the fused kernels are instantiated for; 0 = not supported
     const int k32 = pad32(K);
     if (k32 <= 256) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
@@ -1484,20 +1489,23 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
 
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
     if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
-    if (Kp <= 256) {
-        switch (Kp / 32) {
-            case 1: return launch_check_kt<1>(W, H, X, Mp, Np, Kp, part, stream);
-            case 2: return launch_check_kt<2>(W, H, X, Mp, Np, Kp, part, stream);
-            case 4: return launch_check_kt<4>(W, H, X, Mp, Np, Kp, part, stream);
-            case 8: return launch_check_kt<8>(W, H, X, Mp, Np, Kp, part, stream);
+    if (use_k16(Kp)) {
+        switch (Kp / 64) {
+            case 1: return launch_check_k16<1, 2>(W, H, X, Mp, Np, Kp, part, stream);
+            case 2: return launch_check_k16<2, 2>(W, H, X, Mp, Np, Kp, part, stream);
+            case 4: return launch_check_k16<4, 2>(W, H, X, Mp, Np, Kp, part, stream);
+            case 5: return launch_check_k16<5, 1>(W, H, X, Mp, Np, Kp, part, stream);
+            case 6: return launch_check_k16<6, 1>(W, H, X, Mp, Np, Kp, part, stream);
+            case 7: return launch_check_k16<7, 1>(W, H, X, Mp, Np, Kp, part, stream);
+            case 8: return launch_check_k16<8, 1>(W, H, X, Mp, Np, Kp, part, stream);
             default: return hipErrorInvalidValue;
         }
     }
-    switch (Kp / 64) {
-        case 5: return launch_check_k16<5>(W, H, X, Mp, Np, Kp, part, stream);
-        case 6: return launch_check_k16<6>(W, H, X, Mp, Np, Kp, part, stream);
-        case 7: return launch_check_k16<7>(W, H, X, Mp, Np, Kp, part, stream);
-        case 8: return launch_check_k16<8>(W, H, X, Mp, Np, Kp, part, stream);
+    switch (Kp / 32) {
+        case 1: return launch_check_kt<1>(W, H, X, Mp, Np, Kp, part, stream);
+        case 2: return launch_check_kt<2>(W, H, X, Mp, Np, Kp, part, stream);
+        case 4: return launch_check_kt<4>(W, H, X, Mp, Np, Kp, part, stream);
+        case 8: return launch_check_kt<8>(W, H, X, Mp, Np, Kp, part, stream);
         default: return hipErrorInvalidValue;
     }
 }

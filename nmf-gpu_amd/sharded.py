@@ -99,7 +99,11 @@ class GpuShard:
 
     def __init__(self, M: int, N_local: int, K: int, device: int = 0, **solver_kw):
         import torch
+        from . import api
         from .api import Solver
+        if api._lib is not None and api._loaded_before_torch:
+            raise RuntimeError("libnmf_mi355x.so was loaded before torch: the process now has two HIP runtimes and a torch "
+                               "stream cannot be shared with it; import torch before the first nmf_gpu_amd call")
         self.torch = torch
         self.device = device
         self.stream = torch.cuda.Stream(device=device)

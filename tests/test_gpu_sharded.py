@@ -49,7 +49,7 @@ def _worker(rank, world, port, M, N, K, iters, q):
 
 @pytest.mark.parametrize("N", [512, 333])
 def test_two_ranks_one_gpu_match_oracle(oracle, N):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp   # not torch.multiprocessing: torch must not enter this process after libnmf (two HIP runtimes)
     M, K, iters, world = 256, 64, 10, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -90,7 +90,7 @@ def _worker(rank, world, port, M, N, K, iters, q):
 
 @pytest.mark.parametrize("world,N", [(2, 96), (3, 100)])
 def test_sharded_loop_matches_single_process(oracle, world, N):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     M, K, iters = 64, 8, 10
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
