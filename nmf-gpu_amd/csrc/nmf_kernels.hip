@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             float ar[D];
 #pragma unroll
             for (int e = 0; e < D; ++e) ar[e] = lds_ld(b1 + (64 * ((e >> 1) >> 4) + ((e >> 1) & 15)) * kLdv + 16 * (e & 1));
+            if (OCC > 1) __builtin_amdgcn_s_setprio(1);
             f32x4 s0, s1;
             constexpr int NLOAD = NST + 2;
             constexpr int G = E1 / (NLOAD + 1);
@@ -1183,6 +1184,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 }
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+            if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             if (CHECK) {
                 float fkl = 0.f, fd = 0.f, fx = 0.f;
 #pragma unroll
@@ -1209,6 +1211,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             for (int r = 0; r < 8; ++r) z[r] = quotient<DIV>(xr[r], clamp_eps(r < 4 ? s0[r] : s1[r - 4]));
             __builtin_amdgcn_sched_barrier(0);
             x_relayout();
+            if (OCC > 1) __builtin_amdgcn_s_setprio(1);
             // ---- product 2: NT independent accumulators
             constexpr int E0 = E2 / 8;
 #pragma unroll
@@ -1227,6 +1230,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     }
                 }
             }
+            if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
     }
