@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz
 # HBM bytes per fused_step launch at cfg3 from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
 # profiles/r01_pmc_summary.md).  bench.py cannot collect PMC itself; other shapes report null.
-PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.404e9, "W": 1.234e9}}
+PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.369e9, "W": 1.211e9}}
 
 
 def synth(seed, rows, cols):

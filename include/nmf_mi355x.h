@@ -96,9 +96,13 @@ typedef struct {
     void *comm;             /* nmf_comm* for an N-sharded run (see nmf_comm_*), NULL = single GPU */
     int   nsplit_h;         /* 0 = auto; split count of the reduction dim in the H / W step */
     int   nsplit_w;
-    int   fast_divide;      /* 0 (default): X ./ WH by correctly rounded IEEE division (cuda/matrix.cu:149);
-                             * 1: reciprocal refined to <= 1 ulp, bit-identical on 3e9 sampled operand pairs,
-                             *    ~2.5 % faster; differs only where x/y overflows or is subnormal */
+    int   fast_divide;      /* 0 (default): X ./ WH correctly rounded (IEEE division, cuda/matrix.cu:149).  The fused kernel
+                             *    omits the range-scaling steps of the division sequence for waves whose operands are all
+                             *    in [EPS, 2^60] (X checked at upload, W*H per 32-row chunk) -- there they are the identity,
+                             *    so the quotient is bit-identical -- and runs the full sequence everywhere else;
+                             * -1: always the full sequence (for A/B tests of the above);
+                             * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
+                             *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
 } nmf_opts;
 
 #define NMF_MAX_KL 64

@@ -370,7 +370,7 @@ class Solver:
 
     def __init__(self, M: int, N: int, K: int, *, path: int = PATH_AUTO, use_graph: bool = True,
                  device: int = -1, stream: Optional[int] = None, comm: Optional[Comm] = None,
-                 nsplit_h: int = 0, nsplit_w: int = 0, fast_divide: bool = False):
+                 nsplit_h: int = 0, nsplit_w: int = 0, fast_divide: int = 0):
         self.M, self.N, self.K = M, N, K
         o = _make_opts(path=path, use_graph=int(use_graph), device=device, stream=stream,
                        comm=(comm._h.value if comm is not None else None), nsplit_h=nsplit_h, nsplit_w=nsplit_w,

@@ -96,6 +96,8 @@ struct nmf_solver {
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
     int fast_divide = 0;
+    int x_in_range = 0;            // X verified at upload: every entry 0 or in [EPS, 2^60] (FusedArgs::x_in_range)
+    unsigned *range_flag = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
@@ -213,6 +215,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
     HIPCHK(hipMalloc((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups));
     HIPCHK(hipMalloc((void **)&s->chk_out, sizeof(double) * 3));
     HIPCHK(hipHostMalloc((void **)&s->chk_host, sizeof(double) * 3, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&s->range_flag, sizeof(unsigned)));
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
     if ((size_t)K * N > s->staging_count) s->staging_count = (size_t)K * N;
@@ -235,6 +238,7 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->chk_part) (void)hipFree(s->chk_part);
     if (s->chk_out) (void)hipFree(s->chk_out);
     if (s->chk_host) (void)hipHostFree(s->chk_host);
+    if (s->range_flag) (void)hipFree(s->range_flag);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -255,8 +259,17 @@ static int upload_one(nmf_solver *s, float *dst, int rows_p, int cols_p, const f
         HIPCHK(hipMemcpyAsync(s->staging, src, (size_t)rows * cols * sizeof(float), hipMemcpyHostToDevice, s->stream));
         d = s->staging;
     }
-    HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, s->stream));
-    if (host) HIPCHK(hipStreamSynchronize(s->stream));   // staging is reused by the next matrix
+    const bool is_x = dst == s->X;
+    if (is_x) HIPCHK(hipMemsetAsync(s->range_flag, 0, sizeof(unsigned), s->stream));
+    HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, is_x ? s->range_flag : nullptr, s->stream));
+    if (is_x) {
+        unsigned flag = 1;
+        HIPCHK(hipMemcpyAsync(&flag, s->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->x_in_range = flag == 0;
+    } else if (host) {
+        HIPCHK(hipStreamSynchronize(s->stream));   // staging is reused by the next matrix
+    }
     return NMF_OK;
 }
 
@@ -321,7 +334,8 @@ static FusedArgs fused_args(nmf_solver *s) {
     FusedArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.norm = nullptr;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide > 0;
+    a.x_in_range = s->fast_divide < 0 ? 0 : s->x_in_range;
     return a;
 }
 
@@ -647,6 +661,17 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
+                if (which == 4001 || which == 4002) {   // 4001: slice i (of 64) of the exhaustive significand-pair comparison; 4002: rcp exponent invariance
+                    if (i == 0) HIPCHK(hipMemsetAsync(s->chk_part, 0, 80, st));
+                    HIPCHK(launch_divide_exhaustive((unsigned long long *)s->chk_part, which == 4002 ? -1 : i, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    unsigned long long c[10];
+                    HIPCHK(hipMemcpy(c, s->chk_part, 80, hipMemcpyDeviceToHost));
+                    if (which == 4002) { fprintf(stderr, "rcp exponent invariance: %llu of %llu (significand, exponent) cases differ\n", c[0], (1ull << 23) * 123); break; }
+                    fprintf(stderr, "divide exhaustive: slice %d/%d done, %llu mismatches in %llu pairs so far\n", i + 1, reps, c[0], c[1]);
+                    for (unsigned long long k = 0; k < c[0] && k < 8; ++k) fprintf(stderr, "    mismatch at mx=0x%06llx my=0x%06llx\n", c[2 + k] >> 32, c[2 + k] & 0xFFFFFFFFull);
+                    break;
+                }
                 if (which == 4000) {   // IEEE vs refined-reciprocal quotient: mismatch census over ~1e9 operand pairs
                     HIPCHK(hipMemsetAsync(s->chk_part, 0, 16, st));
                     HIPCHK(launch_divide_compare((unsigned long long *)s->chk_part, 12345u + (unsigned)i, st));

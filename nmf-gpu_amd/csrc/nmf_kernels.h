@@ -29,13 +29,16 @@ struct FusedArgs {
     int Mp, Np, Kp;
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
-    int fast_divide;          // 1: refined-reciprocal quotient instead of IEEE division (v3 kernel only)
+    int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
+    int x_in_range;           // 1: every entry of X is 0 or in [EPS, 2^60] (checked at upload): the 16-column kernel may
+                              //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe
 hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream);   // micro-probe 2
 hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream);   // diagnostic stamps
 hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipStream_t stream);   // diagnostic
+hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream);     // diagnostic (slice -1: rcp invariance)
 hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream);   // timing probes (v1 kernel + ablation mask)
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
@@ -82,7 +85,8 @@ hipError_t launch_kl_reduce(const float *x, const float *y, size_t n, double *pa
 // ---------------------------------------------------------------- padding helpers
 // dst (rows_p x cols_p, ld = rows_p) <- src (rows x cols, ld = rows), zero padding, optional EPS clamp of the
 // valid region (read_matrix's set_epsilon, cuda/nmf.cu:211)
-hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp,
+// range_flag (may be null): set to 1 if any copied value is NaN or > 2^60
+hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp, unsigned *range_flag,
                            hipStream_t stream);
 hipError_t launch_unpad_copy(float *dst, int rows, int cols, const float *src, int rows_p, hipStream_t stream);
 

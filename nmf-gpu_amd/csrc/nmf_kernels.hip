@@ -46,6 +46,8 @@ __device__ __forceinline__ constexpr int rho(int r) { return (r & 3) + 8 * (r >>
 
 // set_epsilon semantics (cuda/matrix.cu:185-186): a clamp, NaN passes through.
 __device__ __forceinline__ float clamp_eps(float v) { return (v < kEps) ? kEps : v; }
+// operands in [EPS, 2^60] (or a zero numerator) never trigger the range scaling of the IEEE division sequence
+constexpr float kDivSafeMax = 1152921504606846976.0f;   // 2^60
 
 // 64-lane sum, result valid in lane 0
 __device__ __forceinline__ float wave_sum(float v) {
@@ -564,6 +566,61 @@ __device__ __forceinline__ float quotient(float x, float y) {
     return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
 }
 
+// Eight quotients z[r] = x[r] / max(s[r], EPS) of one lane (one chunk of the 16-column kernel).
+// DIV = 1: quotient<1> each, unconditionally.  DIV = 0: correctly rounded.  hipcc expands `/` into
+//     ys = div_scale(y), xs = div_scale(x), r0 = rcp(ys), r = fma(fma(-ys, r0, 1), r0, r0), q = xs * r,
+//     q = fma(fma(-ys, q, xs), r, q), q = div_fmas(fma(-ys, q, xs), r, q), div_fixup(q, y, x)      (11 VALU + 2 for the clamp)
+// whose div_scale / div_fmas / div_fixup only act when an operand or the quotient leaves the normal range, and whose
+// last correction never changes the result there: quotient<1> (6 VALU) returns the same bits for EVERY pair of fp32
+// significands -- all 2^46 enumerated on the device, and v_rcp_f32 checked exponent-invariant (tools/divide_exhaustive.py,
+// profiles/r01_divide_exhaustive.log) -- hence for every x = 0 or x, y in [EPS, 2^60], where operands, quotient and
+// remainders stay normal and every step is exponent-invariant.  X is range-checked once at upload (in_range); the
+// denominators per chunk with one integer max over the lane's 8 raw dot products (NaN and negative bit patterns
+// compare high).  A wave with everything in range takes quotient<1> behind a one-instruction clamp (v_max_f32 equals
+// `s < EPS ? EPS : s` for the non-NaN values that pass the guard); any other wave runs the full sequence.  The f32 MFMA
+// shares the VALU datapath (profiles/r01_pmc_summary.md): every VALU instruction saved here is MFMA issue time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int DIV>
+__device__ __forceinline__ void quotient8(const float (&x)[8], const f32x4 &s0, const f32x4 &s1, float (&z)[8], bool in_range) {
+    if (DIV == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[r] = quotient<1>(x[r], clamp_eps(r < 4 ? s0[r] : s1[r - 4]));
+        return;
+    }
+    unsigned m = __float_as_uint(s0[0]);
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { const unsigned b = __float_as_uint(r < 4 ? s0[r] : s1[r - 4]); m = b > m ? b : m; }
+    const bool fast = in_range && __builtin_amdgcn_ballot_w64(m > __float_as_uint(kDivSafeMax)) == 0;
+    if (fast) {
+        // quotient<1>, stage by stage over the eight operands so that no instruction waits on its predecessor
+        const float eps = kEps;
+        float y[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(y[r]) : "v"(r < 4 ? s0[r] : s1[r - 4]), "v"(eps));
+        f32x2 yy[4], xx[4], rc[4], q[4], e[4];
+        const f32x2 one = {1.0f, 1.0f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { yy[i] = f32x2{y[2 * i], y[2 * i + 1]}; xx[i] = f32x2{x[2 * i], x[2 * i + 1]}; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rc[i] = f32x2{__builtin_amdgcn_rcpf(yy[i].x), __builtin_amdgcn_rcpf(yy[i].y)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_elementwise_fma(-yy[i], rc[i], one);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rc[i] = __builtin_elementwise_fma(e[i], rc[i], rc[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = xx[i] * rc[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_elementwise_fma(-yy[i], q[i], xx[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(e[i], rc[i], q[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { z[2 * i] = q[i].x; z[2 * i + 1] = q[i].y; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[r] = x[r] / clamp_eps(r < 4 ? s0[r] : s1[r - 4]);
+    }
+}
+
 // STAMP = true: diagnostic build only (never the shipped path): s_memtime stamps around the five segments of a
 // chunk, summed per wave and written to a.partials as 5 x uint64 per wave; the results of the step stay valid.
 #define NMF_STAMP(var)                                                                                     \
@@ -1022,6 +1079,43 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
     return hipGetLastError();
 }
 
+// Diagnostic: EXHAUSTIVE comparison of quotient<1> with the IEEE quotient over every pair of fp32 significands
+// (2^23 x 2^23; x = 1.mx, y = 1.my).  All operations of both sequences are exponent-invariant while operands,
+// quotient and remainders stay normal (rcp checked separately below), so zero mismatches here proves the two
+// bit-identical for every x, y in [EPS, 2^60].  One launch covers 2^17 denominators (slice of 64).
+// counts[0] = mismatches, counts[1] = pairs compared, counts[2..] = first mismatching (mx, my) pairs.
+__global__ __launch_bounds__(256) void divide_exhaustive_kernel(unsigned long long *counts, unsigned slice) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;            // 2^20 threads
+    const unsigned my = (slice << 17) | (t >> 3);
+    const unsigned x0 = (t & 7u) << 20;
+    const float y = __uint_as_float(0x3F800000u | my);
+    unsigned bad = 0, first = 0xFFFFFFFFu;
+    for (unsigned i = 0; i < (1u << 20); ++i) {
+        const float x = __uint_as_float(0x3F800000u | (x0 + i));
+        const float q0 = quotient<0>(x, y), q1 = quotient<1>(x, y);
+        if (__float_as_uint(q0) != __float_as_uint(q1)) { ++bad; if (first == 0xFFFFFFFFu) first = x0 + i; }
+    }
+    if (bad) {
+        const unsigned long long slot = atomicAdd(&counts[0], (unsigned long long)bad);
+        if (slot < 8) counts[2 + slot] = ((unsigned long long)first << 32) | my;
+    }
+    if (threadIdx.x == 0) atomicAdd(&counts[1], 256ull << 20);
+}
+// v_rcp_f32 is exponent-invariant: rcp(m * 2^e) == rcp(m) * 2^-e for every significand and e in [-61, 61]
+__global__ __launch_bounds__(256) void rcp_invariance_kernel(unsigned long long *counts) {
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;            // 2^23 threads
+    const float y = __uint_as_float(0x3F800000u | m);
+    const float r = __builtin_amdgcn_rcpf(y);
+    unsigned bad = 0;
+    for (int e = -61; e <= 61; ++e) bad += __float_as_uint(__builtin_amdgcn_rcpf(ldexpf(y, e))) != __float_as_uint(ldexpf(r, -e));
+    if (bad) atomicAdd(&counts[0], (unsigned long long)bad);
+}
+hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream) {
+    if (slice < 0) hipLaunchKernelGGL(rcp_invariance_kernel, dim3(1u << 15), dim3(256), 0, stream, counts);
+    else hipLaunchKernelGGL(divide_exhaustive_kernel, dim3(4096), dim3(256), 0, stream, counts, (unsigned)slice);
+    return hipGetLastError();
+}
+
 // =====================================================================================
 // Fused half-step for 256 < K <= 512 (BASELINE config 5 has R = 512): same algorithm as v3 on
 // v_mfma_f32_16x16x4_f32 with 16 owned columns per wave, so that the K x 16 accumulator (16*NB
@@ -1036,6 +1130,7 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
 // of 16 (16-B loads of the owned factor) and, with 33-float LDS rows, 32 distinct banks per half-wave.
 // CHECK = true turns the kernel into the KL / rel-L1 check (product 1 only), see check_kernel.
 // =====================================================================================
+typedef const __attribute__((address_space(1))) char *global_bytes;
 #define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int kXt16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
 
@@ -1052,6 +1147,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     const int P = WSTEP ? a.Np : a.Mp;
     const int Q = WSTEP ? a.Mp : a.Np;
     const int nsplit = a.nsplit;
+    const bool x_in_range = a.x_in_range != 0;
     const int split = blockIdx.x % nsplit;
     const int qblk = blockIdx.x / nsplit;
     int q0 = (qblk * 4 + wave) * 16;
@@ -1115,8 +1211,18 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             vcur = reinterpret_cast<const char *>(V) + (size_t)ch * vchunk;
             xcur = xbase + (size_t)ch * xchunk;
         };
-        auto stage_load_one = [&](int q) { st[q] = *reinterpret_cast<const f32x4 *>((vcur + (size_t)q * (size_t)vstep) + vo); };
-        auto x_load_one = [&](int i) { xg[i] = *reinterpret_cast<const f32x4 *>((xcur + (size_t)i * (size_t)xstep) + xo); };
+        // the uniform part of every address is pinned in an SGPR pair (scalar adds are free next to the MFMAs;
+        // left alone the compiler chains 64-bit VALU adds through the per-lane address instead)
+        auto stage_load_one = [&](int q) {
+            global_bytes base = (global_bytes)(vcur + (size_t)q * (size_t)vstep);
+            asm volatile("" : "+s"(base));
+            st[q] = *(const __attribute__((address_space(1))) f32x4 *)(base + vo);
+        };
+        auto x_load_one = [&](int i) {
+            global_bytes base = (global_bytes)(xcur + (size_t)i * (size_t)xstep);
+            asm volatile("" : "+s"(base));
+            xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
+        };
         auto stage_store_one = [&](float *__restrict__ vl, int w) {
             const int q = w / 4, cc = w % 4;
             if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
@@ -1207,8 +1313,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
             float z[8];
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) z[r] = quotient<DIV>(xr[r], clamp_eps(r < 4 ? s0[r] : s1[r - 4]));
+            quotient8<DIV>(xr, s0, s1, z, x_in_range);
             __builtin_amdgcn_sched_barrier(0);
             x_relayout();
             if (OCC > 1) __builtin_amdgcn_s_setprio(1);
@@ -1308,7 +1413,7 @@ template <int NB, int OCC>
 static hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
     FusedArgs a;
     a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
-    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
+    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, lds);
     if (e != hipSuccess) return e;
@@ -1473,7 +1578,7 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
     if (fused_variant() != 1 && (size_t)Kp * (size_t)Mp < ((size_t)1 << 31)) {
         FusedArgs a;
         a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
-        a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0;
+        a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
         const size_t lds3 = (size_t)2 * KT * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
         {
             hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, lds3);
@@ -1897,20 +2002,25 @@ hipError_t launch_row_div(const float *a, const float *b, float *c, int rows, in
 // Padding
 // =====================================================================================
 __global__ __launch_bounds__(256) void pad_copy_kernel(float *__restrict__ dst, int rows_p, int cols_p, const float *__restrict__ src, int rows, int cols,
-                                                       int clamp) {
+                                                       int clamp, unsigned *__restrict__ range_flag) {
     const size_t n = (size_t)rows_p * cols_p;
+    bool out_of_range = false;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
         const int i = (int)(e % (size_t)rows_p), j = (int)(e / (size_t)rows_p);
         float v = 0.f;
         if (i < rows && j < cols) {
             v = src[(size_t)i + (size_t)j * rows];
             if (clamp) v = clamp_eps(v);
+            out_of_range |= !(v <= kDivSafeMax);      // NaN counts as out of range
         }
         dst[e] = v;
     }
+    if (range_flag && out_of_range) atomicOr(range_flag, 1u);
 }
-hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp, hipStream_t stream) {
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(ew_grid((size_t)rows_p * cols_p)), dim3(256), 0, stream, dst, rows_p, cols_p, src, rows, cols, clamp ? 1 : 0);
+hipError_t launch_pad_copy(float *dst, int rows_p, int cols_p, const float *src, int rows, int cols, bool clamp, unsigned *range_flag,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(ew_grid((size_t)rows_p * cols_p)), dim3(256), 0, stream, dst, rows_p, cols_p, src, rows, cols,
+                       clamp ? 1 : 0, range_flag);
     return hipGetLastError();
 }
 

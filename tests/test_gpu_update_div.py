@@ -244,6 +244,56 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     print("cfg3 K_par=2 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
 
 
+def test_cfg3_200_iterations_kl_monotone(ng):
+    """SURVEY 8(d) gate for the shapes the CPU cannot iterate 200 times: the full 200-iteration run at
+    BASELINE config 3, KL checked every 25 iterations, must decrease at every check and stay finite."""
+    M, N, K = 4096, 65536, 256
+    rng = np.random.default_rng(3)
+    s = ng.Solver(M, N, K)
+    s.upload(np.asfortranarray(rng.random((M, K), dtype=np.float32)), np.asfortranarray(rng.random((K, N), dtype=np.float32)),
+             np.asfortranarray(rng.random((M, N), dtype=np.float32)))
+    r = s.run(1e-30, 200, 25)            # a threshold no decreasing sequence reaches: checks on, no early stop
+    W, H = s.download()
+    s.close()
+    kl = np.asarray(r["kl"])
+    assert r["iterations"] == 200 and len(kl) == 9            # iteration 0 + 8 checks
+    assert np.all(np.diff(kl) < 0) and kl[-1] > 0 and np.isfinite(kl).all()
+    assert np.isfinite(W).all() and np.isfinite(H).all() and W.min() >= 0 and H.min() >= 0
+
+
+def test_cfg5_tall_skinny_r512(ng, oracle):
+    """BASELINE config 5 (M=8192, N=131072, R=512; K > 256 takes the 16x16x4 kernel with NB = 8).  The shard one
+    of 8 GPUs owns (N/8 = 16384 columns) is checked against the oracle after K_par = 1 iteration; the unsharded
+    problem (X = 4 GiB) is checked through the update's conservation invariants and KL monotonicity."""
+    M, N, K = 8192, 131072, 512
+    rng = np.random.default_rng(5)
+    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    ns = N // 8
+    s = ng.Solver(M, ns, K)
+    s.upload(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]))
+    s.iterate(1)
+    Wg, Hg = s.download()
+    s.close()
+    Wr, Hr, _, _ = oracle.update_div(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]), 0.0, 1, 25)
+    print("cfg5 shard K_par=1 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    kl0, _ = s.check()
+    s.update_h()
+    W1, H1 = s.download()
+    assert np.allclose(W1.astype(np.float64).sum(axis=0) @ H1.astype(np.float64), X.sum(axis=0, dtype=np.float64), rtol=2e-5)
+    s.update_w()
+    W2, H2 = s.download()
+    assert np.allclose(W2.astype(np.float64) @ H2.astype(np.float64).sum(axis=1), X.sum(axis=1, dtype=np.float64), rtol=2e-5)
+    kl1, _ = s.check()
+    s.iterate(2)
+    kl2, _ = s.check()
+    s.close()
+    assert kl0 > kl1 > kl2 > 0
+
+
 def test_cli_reference_workflow(ng, oracle, tmp_path):
     """The reference's workflow (matrix_export.py -> ./nmf -> Wout/Hout, cuda/nmf.cu:30-51) with the
     shipped CLI: same .bin files in, same .bin files out, checked by tolerance instead of md5."""
@@ -424,3 +474,54 @@ def test_cli_verbose_lines(ng, oracle, tmp_path):
     kls = [float(l.split("kl-divergence")[1].split()[0]) for l in lines]
     _, _, _, klr = oracle.update_div(W, H, X, 1e-9, 50, 25)
     assert np.allclose(kls, klr, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,iters", [(1024, 4096, 64, 200), (300, 520, 128, 30), (256, 384, 512, 10), (4096, 65536, 256, 1)])
+def test_range_guarded_division_is_bit_identical_to_the_full_sequence(ng, M, N, K, iters):
+    """Default division (range scaling skipped for waves whose operands are all in [EPS, 2^60]) against
+    nmf_opts.fast_divide = -1 (always the complete IEEE sequence): the same bits, not a tolerance."""
+    rng = np.random.default_rng(11)
+    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    X[rng.random((M, N)) < 0.01] = 0.0                       # exact zeros are clamped to EPS at upload
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    outs = []
+    for fd in (0, -1):
+        s = ng.Solver(M, N, K, fast_divide=fd)
+        assert s.path == ng.PATH_FUSED
+        s.upload(W, H, X)
+        s.iterate(iters)
+        outs.append(s.download())
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("case", ["x_huge", "wh_huge", "some_columns_huge", "x_tiny"])
+def test_division_operands_outside_the_guard_range(ng, oracle, case):
+    """Operands the guard must hand to the full division sequence: X beyond 2^60 (flagged at upload), W*H beyond
+    2^60 everywhere, and only under a few columns (some waves inside the range, some outside)."""
+    M, N, K = 192, 320, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=21)
+    if case == "x_huge":
+        X = np.asfortranarray(X * np.float32(1e30))
+    elif case == "x_tiny":
+        X = np.asfortranarray(X * np.float32(1e-30))          # below EPS: clamped, stays in range
+    elif case == "wh_huge":
+        W = np.asfortranarray(W * np.float32(1e12)); H = np.asfortranarray(H * np.float32(1e12))
+    else:
+        H = H.copy(order="F"); H[:, 5:9] *= np.float32(1e25); H[:, 200] *= np.float32(1e30)
+    outs = []
+    for fd in (0, -1):
+        s = ng.Solver(M, N, K, path=ng.PATH_FUSED, use_graph=False, fast_divide=fd)
+        s.upload(W, H, X)
+        s.update_h()
+        _, H1 = s.download()
+        s.update_w()
+        W2, _ = s.download()
+        s.close()
+        outs.append((W2, H1))
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    Wr = oracle.update_w(oracle.clamp(W), Hr, oracle.clamp(X))
+    assert np.isfinite(Hr).all() and np.isfinite(Wr).all()
+    assert oracle.relF(outs[0][1], Hr) < 5e-6 and oracle.relF(outs[0][0], Wr) < 5e-6
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

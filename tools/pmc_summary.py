@@ -1,0 +1,45 @@
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one directory per counter group) into markdown tables.
+    python tools/pmc_summary.py gpurun_out/pmc6_fetch gpurun_out/pmc6_write gpurun_out/pmc6_sq gpurun_out/pmc6_insts
+Per kernel name: mean counter value per dispatch (and mean duration from the dispatch timestamps)."""
+import csv, glob, os, sys
+from collections import defaultdict
+
+val = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> values
+dur = defaultdict(list)
+for d in sys.argv[1:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            val[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if (f, r["Dispatch_Id"]) not in seen and "SQ_WAVE_CYCLES" == r["Counter_Name"]:
+                seen.add((f, r["Dispatch_Id"]))
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+mean = lambda v: sum(v) / len(v) if v else float("nan")
+ks = [k for k in val if "nmf::" in k]
+print("| kernel | FETCH_SIZE raw KB | WRITE_SIZE KB | HBM bytes per launch = (2*FETCH + WRITE)*1024 |\n|---|---|---|---|")
+for k in sorted(ks):
+    c = val[k]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fe, wr = mean(c["FETCH_SIZE"]), mean(c["WRITE_SIZE"])
+        print(f"| `{k.split('(')[0]}` | {fe:.0f} | {wr:.0f} | {(2 * fe + wr) * 1024 / 1e9:.3f} GB |")
+print()
+for k in sorted(ks):
+    c = val[k]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "fused_step" not in k:
+        continue
+    g, w = mean(c["GRBM_GUI_ACTIVE"]) / 8, mean(c["SQ_WAVE_CYCLES"])     # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    ms = mean(dur[k])
+    # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD and is summed over the chip: 256 CUs x 4 SIMDs x kernel cycles = 100 %
+    print(f"* `{k.split('(')[0]}`: {ms:.3f} ms under the profiler, clock {g / ms / 1e6:.3f} GHz; SQ_VALU_MFMA_BUSY_CYCLES {mean(c['SQ_VALU_MFMA_BUSY_CYCLES']):.3e}"
+          f" = **{100 * mean(c['SQ_VALU_MFMA_BUSY_CYCLES']) / (g * 1024):.1f} % of SIMD-cycles**; of wave-cycles: SQ_WAIT_ANY {100 * mean(c['SQ_WAIT_ANY']) / w:.1f} %,"
+          f" SQ_WAIT_INST_ANY {100 * mean(c['SQ_WAIT_INST_ANY']) / w:.1f} %, SQ_ACTIVE_INST_ANY {100 * mean(c['SQ_ACTIVE_INST_ANY']) / w:.1f} %,"
+          f" SQ_ACTIVE_INST_VALU {100 * mean(c['SQ_ACTIVE_INST_VALU']) / w:.1f} %; SQ_LDS_BANK_CONFLICT {mean(c['SQ_LDS_BANK_CONFLICT']):.2e} of SQ_LDS_IDX_ACTIVE {mean(c['SQ_LDS_IDX_ACTIVE']):.2e}")
+print()
+for k in sorted(ks):
+    c = val[k]
+    if "SQ_INSTS_MFMA" not in c or "fused_step" not in k:
+        continue
+    mf, va = mean(c["SQ_INSTS_MFMA"]), mean(c["SQ_INSTS_VALU"])
+    print(f"* `{k.split('(')[0]}`: MFMA {mf:.3e}, VALU incl. MFMA {va:.3e} (non-MFMA VALU per MFMA: {(va - mf) / mf:.2f}), LDS {mean(c['SQ_INSTS_LDS']):.3e},"
+          f" VMEM {mean(c['SQ_INSTS_VMEM']):.3e}, SALU {mean(c['SQ_INSTS_SALU']):.3e}")
