@@ -661,15 +661,15 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
-                if (which == 4001 || which == 4002) {   // 4001: slice i (of 64) of the exhaustive significand-pair comparison; 4002: rcp exponent invariance
-                    if (i == 0) HIPCHK(hipMemsetAsync(s->chk_part, 0, 80, st));
-                    HIPCHK(launch_divide_exhaustive((unsigned long long *)s->chk_part, which == 4002 ? -1 : i, st));
+                if (which >= 4001 && which <= 4004) {   // 4003: the 4-instruction variant   // 4001: slice i (of 64) of the exhaustive significand-pair comparison; 4002: rcp exponent invariance
+                    if (i == 0) HIPCHK(hipMemsetAsync(s->chk_part, 0, 88, st));
+                    HIPCHK(launch_divide_exhaustive((unsigned long long *)s->chk_part, which == 4002 ? -1 : (which == 4003 ? 64 + i : (which == 4004 ? 128 + i : i)), st));
                     HIPCHK(hipStreamSynchronize(st));
-                    unsigned long long c[10];
-                    HIPCHK(hipMemcpy(c, s->chk_part, 80, hipMemcpyDeviceToHost));
+                    unsigned long long c[11];
+                    HIPCHK(hipMemcpy(c, s->chk_part, 88, hipMemcpyDeviceToHost));
                     if (which == 4002) { fprintf(stderr, "rcp exponent invariance: %llu of %llu (significand, exponent) cases differ\n", c[0], (1ull << 23) * 123); break; }
                     fprintf(stderr, "divide exhaustive: slice %d/%d done, %llu mismatches in %llu pairs so far\n", i + 1, reps, c[0], c[1]);
-                    for (unsigned long long k = 0; k < c[0] && k < 8; ++k) fprintf(stderr, "    mismatch at mx=0x%06llx my=0x%06llx\n", c[2 + k] >> 32, c[2 + k] & 0xFFFFFFFFull);
+                    if (i + 1 == reps) for (unsigned long long k = 0; k < c[2] && k < 8; ++k) fprintf(stderr, "    e.g. mismatch at mx=0x%06llx my=0x%06llx\n", c[3 + k] >> 32, c[3 + k] & 0xFFFFFFFFull);
                     break;
                 }
                 if (which == 4000) {   // IEEE vs refined-reciprocal quotient: mismatch census over ~1e9 operand pairs

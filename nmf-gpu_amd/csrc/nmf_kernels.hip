@@ -1083,7 +1083,10 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
 // (2^23 x 2^23; x = 1.mx, y = 1.my).  All operations of both sequences are exponent-invariant while operands,
 // quotient and remainders stay normal (rcp checked separately below), so zero mismatches here proves the two
 // bit-identical for every x, y in [EPS, 2^60].  One launch covers 2^17 denominators (slice of 64).
-// counts[0] = mismatches, counts[1] = pairs compared, counts[2..] = first mismatching (mx, my) pairs.
+// counts[0] = mismatches, counts[1] = pairs compared, counts[2] = threads that saw one, counts[3..10] = the first
+// mismatching (mx, my) of up to 8 of them.  VARIANT 1 (no refinement of the reciprocal, 4 instructions) fails on
+// 47 045 of the 2^46 pairs; VARIANT 2 (x * rcp(y)) is the self-check of the harness (20 % mismatches).
+template <int VARIANT>
 __global__ __launch_bounds__(256) void divide_exhaustive_kernel(unsigned long long *counts, unsigned slice) {
     const unsigned t = blockIdx.x * 256u + threadIdx.x;            // 2^20 threads
     const unsigned my = (slice << 17) | (t >> 3);
@@ -1092,12 +1095,19 @@ __global__ __launch_bounds__(256) void divide_exhaustive_kernel(unsigned long lo
     unsigned bad = 0, first = 0xFFFFFFFFu;
     for (unsigned i = 0; i < (1u << 20); ++i) {
         const float x = __uint_as_float(0x3F800000u | (x0 + i));
-        const float q0 = quotient<0>(x, y), q1 = quotient<1>(x, y);
+        const float q0 = quotient<0>(x, y);
+        float q1;
+        if (VARIANT == 0) q1 = quotient<1>(x, y);
+        else if (VARIANT == 1) {   // 4 instructions: no refinement of the reciprocal
+            const float r = __builtin_amdgcn_rcpf(y), q = x * r;
+            q1 = __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+        } else q1 = x * __builtin_amdgcn_rcpf(y);   // harness self-check: must mismatch often
         if (__float_as_uint(q0) != __float_as_uint(q1)) { ++bad; if (first == 0xFFFFFFFFu) first = x0 + i; }
     }
     if (bad) {
-        const unsigned long long slot = atomicAdd(&counts[0], (unsigned long long)bad);
-        if (slot < 8) counts[2 + slot] = ((unsigned long long)first << 32) | my;
+        atomicAdd(&counts[0], (unsigned long long)bad);
+        const unsigned long long slot = atomicAdd(&counts[2], 1ull);
+        if (slot < 8) counts[3 + slot] = ((unsigned long long)first << 32) | my;
     }
     if (threadIdx.x == 0) atomicAdd(&counts[1], 256ull << 20);
 }
@@ -1112,7 +1122,9 @@ __global__ __launch_bounds__(256) void rcp_invariance_kernel(unsigned long long 
 }
 hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream) {
     if (slice < 0) hipLaunchKernelGGL(rcp_invariance_kernel, dim3(1u << 15), dim3(256), 0, stream, counts);
-    else hipLaunchKernelGGL(divide_exhaustive_kernel, dim3(4096), dim3(256), 0, stream, counts, (unsigned)slice);
+    else if (slice >= 128) hipLaunchKernelGGL(divide_exhaustive_kernel<2>, dim3(4096), dim3(256), 0, stream, counts, (unsigned)slice - 128);
+    else if (slice >= 64) hipLaunchKernelGGL(divide_exhaustive_kernel<1>, dim3(4096), dim3(256), 0, stream, counts, (unsigned)slice - 64);
+    else hipLaunchKernelGGL(divide_exhaustive_kernel<0>, dim3(4096), dim3(256), 0, stream, counts, (unsigned)slice);
     return hipGetLastError();
 }
 
