@@ -34,6 +34,11 @@ struct FusedArgs {
                               //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
+// the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 64 <= Kp <= 512; nmf_fused32.hip: Kp <= 256)
+hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
+hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
+hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
+hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe
 hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream);   // micro-probe 2
 hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream);   // diagnostic stamps
