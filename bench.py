@@ -25,6 +25,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU 
 # HBM bytes per fused_step launch at cfg3 from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
 # profiles/r01_pmc_summary.md).  bench.py cannot collect PMC itself; other shapes report null.
 PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.369e9, "W": 1.211e9}}
+# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of the same launches, same PMC runs
+PMC_MFMA_BUSY = {(4096, 65536, 256): {"H": 0.914, "W": 0.919}}
 
 
 def synth(seed, rows, cols):
@@ -213,6 +215,9 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.md); algorithmic 1.21e9",
+                         "hbm_gbps": (PMC_TRAFFIC_BYTES[(M, Nloc, K)]["H" if ms_h >= ms_w else "W"] / (ms_k * 1e-3) / 1e9) if (M, Nloc, K) in PMC_TRAFFIC_BYTES else None,
+                         "hbm_peak_gbps": 8000.0,
+                         "mfma_busy_pmc": PMC_MFMA_BUSY.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
                          "kernel": "%s (%s-step instantiation, the slower of the two)" % ("fused_step_kernel_v3<KT=1>" if K <= 32 else "fused_step_kernel_k16<NB=%d>" % (-(-K // 64)), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
