@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     double kl = 0.0, dabs = 0.0, xabs = 0.0;
+    // FusedArgs::vsum_part: wave w of q-block b sums row 4 b + w of H over this split's columns
+    const bool vsum_on = WSTEP && PARTIAL && a.vsum_part != nullptr;
+    const int vrow_raw = qblk * 4 + wave, vrow = vrow_raw < K ? vrow_raw : K - 1;
+    float vs_acc = 0.f;
 
     if (c_begin < c_end) {
         const unsigned voff0 = 4u * (WSTEP ? (unsigned)(4 * (tid & 7)) + (unsigned)((tid >> 3) & 31) * (unsigned)ldv
@@ -152,6 +156,9 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             set_chunk(chn);
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
+            // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
+            float vs_in = 0.f;
+            if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
             constexpr int E1 = 2 * N1;
             float ar[D];
 #pragma unroll
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             float z[8];
             __builtin_amdgcn_sched_barrier(0);
             quotient8<DIV>(xr, s0, s1, z, x_in_range);
+            if (WSTEP && PARTIAL) vs_acc += vs_in;
             __builtin_amdgcn_sched_barrier(0);
             x_relayout();
             if (OCC > 1) __builtin_amdgcn_s_setprio(1);
@@ -225,6 +233,13 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             }
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
+        }
+    }
+    if (WSTEP && PARTIAL) {
+        if (vsum_on) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) vs_acc += __shfl_down(vs_acc, off, 32);
+            if (lane == 0 && vrow_raw < K) a.vsum_part[(size_t)split * K + vrow_raw] = vs_acc;
         }
     }
     if (CHECK) {

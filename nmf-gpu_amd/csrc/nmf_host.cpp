@@ -106,6 +106,7 @@ struct nmf_solver {
     float *W = nullptr, *H = nullptr, *X = nullptr;
     float *normW = nullptr, *normH = nullptr, *rowpart = nullptr;
     float *partials = nullptr;     // split slabs
+    float *vsum_part = nullptr;    // nsplit_w x Kp row sums of H per split, written by the W-step kernel (FusedArgs::vsum_part)
     float *psum = nullptr;         // Mp*Kp + Kp floats: [sum_g Z*H' ; rowsum(H)] (all-reduce operand)
     float *psum_owned = nullptr;   // the allocation behind psum unless the caller supplied one
     double *chk_part = nullptr, *chk_out = nullptr, *chk_host = nullptr;
@@ -203,6 +204,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
         if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
         NMFCHK(dev_alloc(&s->partials, pc));
+        if (s->nsplit_w > 1 && fused_streams_vsum(s->Mp, s->Kp)) NMFCHK(dev_alloc(&s->vsum_part, (size_t)s->nsplit_w * s->Kp));
         s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else {
         NMFCHK(dev_alloc(&s->Z, mn));
@@ -233,7 +235,7 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
     if (s->graph8) (void)hipGraphDestroy(s->graph8);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    float *bufs[] = {s->W, s->H, s->X, s->normW, s->normH, s->rowpart, s->partials, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
+    float *bufs[] = {s->W, s->H, s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
     for (float *b : bufs) if (b) (void)hipFree(b);
     if (s->chk_part) (void)hipFree(s->chk_part);
     if (s->chk_out) (void)hipFree(s->chk_out);
@@ -383,13 +385,19 @@ static int enqueue_update_h(nmf_solver *s) {
 static int enqueue_w_partial(nmf_solver *s) {
     hipStream_t st = s->stream;
     const size_t mk = (size_t)s->Mp * s->Kp, mn = (size_t)s->Mp * s->Np;
-    { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->psum + mk, /*clamp=*/false, st)); }
+    // rowsum(H) (the tail of the all-reduce operand) comes out of the W-step kernel where it can (FusedArgs::vsum_part)
+    const bool vs = s->path == NMF_PATH_FUSED && fused_streams_vsum(s->Mp, s->Kp) && (s->nsplit_w == 1 || s->vsum_part);
+    if (!vs) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->psum + mk, /*clamp=*/false, st)); }
     if (s->path == NMF_PATH_FUSED) {
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_w; a.partial = 1;
         a.partials = (s->nsplit_w == 1) ? s->psum : s->partials;
+        if (vs) a.vsum_part = (s->nsplit_w == 1) ? s->psum + mk : s->vsum_part;
         { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
-        if (s->nsplit_w > 1) { PieceScope p(s, NMF_T_APPLY); HIPCHK(launch_sum_partials(s->psum, s->partials, s->nsplit_w, mk, st)); }
+        if (s->nsplit_w > 1) {
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_sum_partials(s->psum, s->partials, s->nsplit_w, mk, st, vs ? s->vsum_part : nullptr, s->Kp));
+        }
     } else {
         PieceScope p(s, NMF_T_W_STEP);
         HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
@@ -417,14 +425,21 @@ static int enqueue_update_w(nmf_solver *s) {
         return enqueue_w_apply(s);
     }
     if (s->path == NMF_PATH_FUSED) {
-        { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_w;
         if (s->nsplit_w == 1) {
+            { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
             a.U_out = s->W; a.norm = s->normH; a.partial = 0;
             PieceScope p(s, NMF_T_W_STEP);
             HIPCHK(launch_fused_step(a, true, st));
+        } else if (s->vsum_part) {
+            // the kernel that streams H anyway also delivers its row sums (one per split); apply_partials finishes them
+            a.partial = 1; a.vsum_part = s->vsum_part;
+            { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, nullptr, s->Mp, s->Np, s->Kp, true, st, s->vsum_part));
         } else {
+            { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
             a.partial = 1;
             { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
             PieceScope p(s, NMF_T_APPLY);

@@ -32,6 +32,9 @@ struct FusedArgs {
     int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
     int x_in_range;           // 1: every entry of X is 0 or in [EPS, 2^60] (checked at upload): the 16-column kernel may
                               //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
+    float *vsum_part = nullptr;   // optional, W-step with partial slabs on the 16-column kernel (fused_streams_vsum()): nsplit x Kp
+                              //    floats receiving, per split, the row sums of the streamed factor H over that split's columns
+                              //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
 // the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 64 <= Kp <= 512; nmf_fused32.hip: Kp <= 256)
@@ -46,16 +49,20 @@ hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipS
 hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream);     // diagnostic (slice -1: rcp invariance)
 hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream);   // timing probes (v1 kernel + ablation mask)
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
+// norm == nullptr (W-step only): the normaliser is max(sum_s vsum_part[s][k], EPS) instead
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
-                                 int Mp, int Np, int Kp, bool wstep, hipStream_t stream);
+                                 int Mp, int Np, int Kp, bool wstep, hipStream_t stream, const float *vsum_part = nullptr);
 // psum = sum_s partials[s]   (sharded W-step: operand of the all-reduce)
-hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream);
+// vsum_part != nullptr: also psum[count + k] = sum_s vsum_part[s][k], k < Kp (the unclamped row sums of H behind the slab sum)
+hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream,
+                               const float *vsum_part = nullptr, int Kp = 0);
 // W[m,k] *= psum[m,k] / max(hsum[k], EPS)
 hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp, int Kp, hipStream_t stream);
 
 // KL(X || max(W*H,EPS)), sum|X-WH|, sum|X| over the valid (non-padded, X > 0) entries:
 // per-workgroup partial triples into `part` (3 doubles per workgroup), then launch_check_final.
 int        check_num_groups(int Np, int Kp);
+bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
 int        fused_pad_k(int K);             // K padded to an instantiated kernel size, 0 if the fused path cannot take it
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,

@@ -22,6 +22,8 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
     return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, part, stream) : launch_check32(W, H, X, Mp, Np, Kp, part, stream);
 }
 
+// one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows
+bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 4 >= (size_t)Kp; }
 int fused_cols_per_group(int Kp) { return use_k16(Kp) ? 64 : 128; }
 int fused_pad_k(int K) {   // padded K the fused kernels are instantiated for; 0 = not supported
     const int k32 = pad32(K);
@@ -34,33 +36,53 @@ int check_num_groups(int Np, int Kp) { return (Np + fused_cols_per_group(Kp) - 1
 // ------------------------------------------------------------------ partial reduce + apply
 template <bool WSTEP>
 __global__ __launch_bounds__(256) void apply_partials_kernel(float *__restrict__ U, const float *__restrict__ P, int nsplit,
-                                                             const float *__restrict__ nrm, size_t count, int Mp, int Kp) {
+                                                             const float *__restrict__ nrm, const float *__restrict__ vsum_part,
+                                                             size_t count, int Mp, int Kp) {
+    int k_cached = -1;
+    float n_cached = 1.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         float s = P[i];
         for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
         const int k = WSTEP ? (int)(i / (size_t)Mp) : (int)(i % (size_t)Kp);
-        U[i] = U[i] * (s / nrm[k]);
+        if (k != k_cached) {
+            k_cached = k;
+            if (vsum_part) {   // row sums of H delivered per split by the W-step kernel: fixed-order sum, then set_epsilon
+                float n = vsum_part[k];
+                for (int sp = 1; sp < nsplit; ++sp) n += vsum_part[(size_t)sp * Kp + k];
+                n_cached = clamp_eps(n);
+            } else n_cached = nrm[k];
+        }
+        U[i] = U[i] * (s / n_cached);
     }
 }
 
 
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm, int Mp, int Np, int Kp,
-                                 bool wstep, hipStream_t stream) {
+                                 bool wstep, hipStream_t stream, const float *vsum_part) {
     const size_t count = wstep ? (size_t)Mp * Kp : (size_t)Kp * Np;
-    if (wstep) hipLaunchKernelGGL(apply_partials_kernel<true>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, count, Mp, Kp);
-    else       hipLaunchKernelGGL(apply_partials_kernel<false>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, count, Mp, Kp);
+    if ((!norm && !vsum_part) || (vsum_part && !wstep)) return hipErrorInvalidValue;
+    if (wstep) hipLaunchKernelGGL(apply_partials_kernel<true>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp);
+    else       hipLaunchKernelGGL(apply_partials_kernel<false>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ out, const float *__restrict__ P, int nsplit, size_t count) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ out, const float *__restrict__ P, int nsplit, size_t count,
+                                                           const float *__restrict__ vsum_part, int Kp) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         float s = P[i];
         for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
         out[i] = s;
     }
+    if (vsum_part) {
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < (size_t)Kp; k += (size_t)gridDim.x * 256) {
+            float n = vsum_part[k];
+            for (int sp = 1; sp < nsplit; ++sp) n += vsum_part[(size_t)sp * Kp + k];
+            out[count + k] = n;
+        }
+    }
 }
-hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, psum, partials, nsplit, count);
+hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream, const float *vsum_part, int Kp) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, psum, partials, nsplit, count, vsum_part, Kp);
     return hipGetLastError();
 }
 

@@ -158,16 +158,19 @@ def test_zero_inputs_are_clamped(ng, oracle):
     _cmp(oracle, Wm.mat, Hm.mat, Wr, Hr, 1e-5)
 
 
-def test_sharded_w_step_single_gpu_emulation(ng, oracle):
+@pytest.mark.parametrize("M,nsplit_w", [(256, 0), (1024, 0), (1024, 1), (1024, 4)])
+def test_sharded_w_step_single_gpu_emulation(ng, oracle, M, nsplit_w):
     """N-sharded W-step emulated on one GPU: two solvers own the two column halves,
-    the host plays the all-reduce on the [Z*H' ; rowsum(H)] buffers."""
+    the host plays the all-reduce on the [Z*H' ; rowsum(H)] buffers.  M = 1024 with K = 64 is tall enough
+    for the W-step kernel to deliver rowsum(H) itself (FusedArgs::vsum_part), with one and with several slabs;
+    M = 256 takes the separate row-sum kernels."""
     import ctypes as C
-    M, N, K = 256, 512, 64
+    N, K = 512, 64
     X, W, H = oracle.gen_problem(M, N, K, seed=4)
     halves = [(0, 200), (200, N)]
     solvers = []
     for (a, b) in halves:
-        s = ng.Solver(M, b - a, K, use_graph=False)
+        s = ng.Solver(M, b - a, K, use_graph=False, nsplit_w=nsplit_w)
         s.upload(W, np.asfortranarray(H[:, a:b]), np.asfortranarray(X[:, a:b]))
         solvers.append(s)
     hip = C.CDLL("libamdhip64.so")
@@ -525,3 +528,22 @@ def test_division_operands_outside_the_guard_range(ng, oracle, case):
     assert np.isfinite(Hr).all() and np.isfinite(Wr).all()
     assert oracle.relF(outs[0][1], Hr) < 5e-6 and oracle.relF(outs[0][0], Wr) < 5e-6
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M,N,K,nsplit_w", [(1024, 700, 64, 3), (2048, 333, 128, 2), (8192, 96, 512, 2), (1000, 260, 64, 4)])
+def test_w_step_row_sums_from_the_streaming_kernel(ng, oracle, M, N, K, nsplit_w):
+    """Shapes tall enough (Mp/64 * 4 >= Kp) for the slab-writing W-step to deliver rowsum(H) per split as a side
+    product of streaming H (FusedArgs::vsum_part) instead of the two row-sum kernels: ragged N (zero-padded columns
+    must not contribute), several slabs, all three NB ranges; against the oracle's sum_rows path."""
+    X, W, H = oracle.gen_problem(M, N, K, seed=31)
+    s = ng.Solver(M, N, K, path=ng.PATH_FUSED, nsplit_w=nsplit_w, use_graph=False)
+    s.upload(W, H, X)
+    s.update_w()
+    W1, H1 = s.download()
+    Wr = oracle.update_w(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert oracle.relF(W1, Wr) < 5e-6 and np.array_equal(H1, oracle.clamp(H))
+    s.iterate(3)
+    Wg, Hg = s.download()
+    s.close()
+    Wo, Ho, _, _ = oracle.update_div(W1, H1, X, 0.0, 3, 25)
+    _cmp(oracle, Wg, Hg, Wo, Ho, 1e-5)
