@@ -5,20 +5,113 @@
 // those stay the defaults, every one of them is a flag here.
 #include "../../include/nmf_mi355x.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--X f] [--W f] [--H f] [--Wout f] [--Hout f] [--iters n] [--thresh x]\n"
             "          [--check n] [--verbose] [--timers] [--path auto|fused|unfused] [--device d]\n"
+            "       %s generate [--M m] [--N n] [--K k] [--seed s] [--X f] [--W f] [--H f]\n"
+            "       %s compare A.bin B.bin [--tol t]\n"
             "defaults follow cuda/nmf.cu:9-11,37-45: ../X.bin ../W.bin ../H.bin -> ../Wout.bin ../Hout.bin,\n"
-            "200 iterations, threshold 0, check every 25.\n", argv0);
+            "200 iterations, threshold 0, check every 25.  `generate` restates matrix_export.py (same bytes for the same\n"
+            "seed and shape, default 4096 x 350, K = 128); `compare` is test_output.sh with a tolerance (rel-Frobenius of A\n"
+            "against B, default 1e-4) instead of an md5.\n", argv0, argv0, argv0);
+}
+
+// matrix_export.py:4-7 restated: numpy.random.seed(s); rand(rows, cols).astype(float32) is MT19937 (init_genrand) with
+// 53-bit doubles (a >> 5, b >> 6), drawn X -> W -> H from one stream; tobytes() of the C-ordered array is written
+// behind the (rows, cols) header and later read as column-major (cuda/nmf.cu:194-204), which is what we reproduce.
+static int write_random(std::mt19937 &g, const char *path, int rows, int cols) {
+    matrix m;
+    int st = nmf_create_matrix(&m, rows, cols, 0.0f);
+    if (st != NMF_OK) return st;
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned a = (unsigned)g() >> 5, b = (unsigned)g() >> 6;
+        m.mat[i] = (float)(((double)a * 67108864.0 + (double)b) / 9007199254740992.0);
+    }
+    st = nmf_write_matrix(m, path);
+    if (st == NMF_OK) printf("wrote %s [%ix%i]\n", path, rows, cols);
+    nmf_destroy_matrix(&m);
+    return st;
+}
+
+static int cmd_generate(int argc, char **argv) {
+    int M = 4096, N = 350, K = 128;
+    unsigned seed = 0;
+    std::string fx = "X.bin", fw = "W.bin", fh = "H.bin";
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(argv[0]); exit(2); } return argv[++i]; };
+        if (a == "--M") M = atoi(next());
+        else if (a == "--N") N = atoi(next());
+        else if (a == "--K") K = atoi(next());
+        else if (a == "--seed") seed = (unsigned)strtoul(next(), nullptr, 10);
+        else if (a == "--X") fx = next();
+        else if (a == "--W") fw = next();
+        else if (a == "--H") fh = next();
+        else { usage(argv[0]); return 2; }
+    }
+    if (M <= 0 || N <= 0 || K <= 0) { fprintf(stderr, "nmf generate: M, N, K must be positive\n"); return 2; }
+    std::mt19937 g(seed);
+    int st;
+    if ((st = write_random(g, fx.c_str(), M, N)) || (st = write_random(g, fw.c_str(), M, K)) || (st = write_random(g, fh.c_str(), K, N))) {
+        fprintf(stderr, "nmf generate: %s (%s)\n", nmf_status_string(st), nmf_last_error());
+        return st;
+    }
+    return 0;
+}
+
+// test_output.sh compares md5s, which no two GEMM implementations can satisfy; this reports rel-Frobenius instead
+static int cmd_compare(int argc, char **argv) {
+    double tol = 1e-4;
+    const char *fa = nullptr, *fb = nullptr;
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--tol") { if (i + 1 >= argc) { usage(argv[0]); return 2; } tol = atof(argv[++i]); }
+        else if (!fa) fa = argv[i];
+        else if (!fb) fb = argv[i];
+        else { usage(argv[0]); return 2; }
+    }
+    if (!fa || !fb) { usage(argv[0]); return 2; }
+    matrix A, B;
+    int st;
+    if ((st = nmf_read_matrix(&A, fa)) || (st = nmf_read_matrix(&B, fb))) {
+        fprintf(stderr, "nmf compare: %s (%s)\n", nmf_status_string(st), nmf_last_error());
+        return st;
+    }
+    if (A.dim[0] != B.dim[0] || A.dim[1] != B.dim[1]) {
+        printf("%s is %ix%i, %s is %ix%i: different\n", fa, A.dim[0], A.dim[1], fb, B.dim[0], B.dim[1]);
+        return 1;
+    }
+    const size_t n = (size_t)A.dim[0] * A.dim[1];
+    double num = 0.0, den = 0.0, maxabs = 0.0;
+    size_t nonfinite = 0;
+    const bool same = memcmp(A.mat, B.mat, n * sizeof(float)) == 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double a = A.mat[i], b = B.mat[i], d = a - b;
+        if (!std::isfinite(a) || !std::isfinite(b)) { ++nonfinite; continue; }
+        num += d * d; den += b * b;
+        if (std::fabs(d) > maxabs) maxabs = std::fabs(d);
+    }
+    const double rel = den > 0.0 ? std::sqrt(num / den) : (num > 0.0 ? INFINITY : 0.0);
+    printf("%s vs %s [%ix%i]: rel-Frobenius %.3e, max |a-b| %.3e, non-finite %zu, bytes %s\n", fa, fb, A.dim[0], A.dim[1], rel, maxabs,
+           nonfinite, same ? "identical" : "differ");
+    const bool ok = nonfinite == 0 && rel <= tol;
+    printf(ok ? "Result matches the test data within %.1e\n" : "Result differs from the test data (tolerance %.1e)\n", tol);
+    nmf_destroy_matrix(&A); nmf_destroy_matrix(&B);
+    return ok ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "generate")) return cmd_generate(argc, argv);
+    if (argc > 1 && !strcmp(argv[1], "compare")) return cmd_compare(argc, argv);
     std::string fx = "../X.bin", fw = "../W.bin", fh = "../H.bin", fwo = "../Wout.bin", fho = "../Hout.bin";
     nmf_opts o;
     nmf_default_opts(&o);

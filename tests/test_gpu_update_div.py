@@ -304,9 +304,9 @@ def test_cli_reference_workflow(ng, oracle, tmp_path):
     from conftest import ROOT
     M, N, K = 512, 350, 64
     X, W, H = oracle.gen_problem(M, N, K, seed=0)
-    for name, A in (("X", X), ("W", W), ("H", H)):
-        oracle.write_bin(str(tmp_path / f"{name}.bin"), A)
     cli = os.path.join(ROOT, "nmf-gpu_amd", "nmf")
+    r = subprocess.run([cli, "generate", "--M", str(M), "--N", str(N), "--K", str(K)], capture_output=True, text=True, timeout=60, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr                       # matrix_export.py's role: X.bin, W.bin, H.bin
     r = subprocess.run([cli, "--X", str(tmp_path / "X.bin"), "--W", str(tmp_path / "W.bin"), "--H", str(tmp_path / "H.bin"),
                         "--Wout", str(tmp_path / "Wout.bin"), "--Hout", str(tmp_path / "Hout.bin"), "--iters", "40", "--timers"],
                        capture_output=True, text=True, timeout=120)
@@ -315,6 +315,11 @@ def test_cli_reference_workflow(ng, oracle, tmp_path):
     Wo, Ho = oracle.read_bin(str(tmp_path / "Wout.bin")), oracle.read_bin(str(tmp_path / "Hout.bin"))
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 40, 25)
     _cmp(oracle, Wo, Ho, Wr, Hr, 1e-5)
+    # test_output.sh's role, by tolerance: against the oracle's result written as the "test" files
+    oracle.write_bin(str(tmp_path / "Wtest.bin"), Wr); oracle.write_bin(str(tmp_path / "Htest.bin"), Hr)
+    for a, b in (("Wout.bin", "Wtest.bin"), ("Hout.bin", "Htest.bin")):
+        r = subprocess.run([cli, "compare", str(tmp_path / a), str(tmp_path / b)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "matches" in r.stdout, r.stdout
     # a missing input is an error with a message, not a crash (the reference never checks fopen, cuda/nmf.cu:196)
     r = subprocess.run([cli, "--X", str(tmp_path / "nope.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "cannot open" in r.stderr
