@@ -103,6 +103,9 @@ typedef struct {
                              * -1: always the full sequence (for A/B tests of the above);
                              * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
                              *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
+    int   restart_lanes;    /* update_div_restarts only: how many initialisations iterate concurrently, each on its own stream
+                             * against the one resident X (small problems fill a fraction of the 256 CUs per launch);
+                             * 0 = automatic (two lanes unless one launch already fills the chip), 1 = one after the other */
 } nmf_opts;
 
 #define NMF_MAX_KL 64

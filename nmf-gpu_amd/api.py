@@ -49,7 +49,7 @@ class _opts(C.Structure):
     _fields_ = [("converge_thresh", C.c_float), ("max_iter", C.c_int), ("iter_check", C.c_int),
                 ("verbose", C.c_int), ("path", C.c_int), ("use_graph", C.c_int), ("device", C.c_int),
                 ("stream", C.c_void_p), ("comm", C.c_void_p), ("nsplit_h", C.c_int), ("nsplit_w", C.c_int),
-                ("fast_divide", C.c_int)]
+                ("fast_divide", C.c_int), ("restart_lanes", C.c_int)]
 
 
 class _result(C.Structure):

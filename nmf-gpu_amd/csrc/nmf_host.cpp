@@ -82,6 +82,7 @@ extern "C" void nmf_default_opts(nmf_opts *o) {
     o->nsplit_h = 0;
     o->nsplit_w = 0;
     o->fast_divide = 0;
+    o->restart_lanes = 0;
 }
 
 static double now_s() {
@@ -96,6 +97,7 @@ struct nmf_solver {
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
     int fast_divide = 0;
+    bool x_shared = false;         // X belongs to another solver (update_div_restarts lanes)
     int x_in_range = 0;            // X verified at upload: every entry 0 or in [EPS, 2^60] (FusedArgs::x_in_range)
     unsigned *range_flag = nullptr;
     hipStream_t stream = nullptr;
@@ -143,7 +145,7 @@ static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
     return ns;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o);
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr);
 
 extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nmf_opts *opts_in) {
     if (!out || M <= 0 || N <= 0 || K <= 0) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
@@ -160,7 +162,7 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     return NMF_OK;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from) {
     const double t0 = now_s();
     s->M = M; s->N = N; s->K = K;
     s->Mp = pad32(M); s->Np = pad32(N);
@@ -185,10 +187,11 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o) {
     const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
     NMFCHK(dev_alloc(&s->W, mk));
     NMFCHK(dev_alloc(&s->H, kn));
-    NMFCHK(dev_alloc(&s->X, mn));
+    if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
+    else NMFCHK(dev_alloc(&s->X, mn));
     HIPCHK(hipMemsetAsync(s->W, 0, mk * sizeof(float), s->stream));
     HIPCHK(hipMemsetAsync(s->H, 0, kn * sizeof(float), s->stream));
-    HIPCHK(hipMemsetAsync(s->X, 0, mn * sizeof(float), s->stream));
+    if (!x_from) HIPCHK(hipMemsetAsync(s->X, 0, mn * sizeof(float), s->stream));
     NMFCHK(dev_alloc(&s->normW, (size_t)s->Kp));
     NMFCHK(dev_alloc(&s->normH, (size_t)s->Kp));
     NMFCHK(dev_alloc(&s->rowpart, (size_t)row_sum_blocks(s->Np) * s->Kp));
@@ -235,7 +238,7 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
     if (s->graph8) (void)hipGraphDestroy(s->graph8);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    float *bufs[] = {s->W, s->H, s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
+    float *bufs[] = {s->W, s->H, s->x_shared ? nullptr : s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
     for (float *b : bufs) if (b) (void)hipFree(b);
     if (s->chk_part) (void)hipFree(s->chk_part);
     if (s->chk_out) (void)hipFree(s->chk_out);
@@ -784,6 +787,51 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
 }
 
 // Multi-restart (paper section 3.2): X resident once, every (W,H) pair through the same loop, best final KL wins.
+// Several solvers iterate side by side, each on its own stream, with solver_run's convergence logic applied per lane:
+// the enqueue of a block of iterations is asynchronous, so the lanes' kernels overlap on the device.
+static int run_lanes(std::vector<nmf_solver *> &lane, int n, float thresh, int max_iter, int iter_check, int verbose, int first_index) {
+    if (iter_check <= 0) iter_check = NMF_ITER_CHECK_DEFAULT;
+    const bool checks = (thresh > 0.f) || verbose;
+    std::vector<double> prev((size_t)n, 0.0);
+    std::vector<char> done((size_t)n, 0);
+    double rl1 = 0.0;
+    if (checks)
+        for (int l = 0; l < n; ++l) {
+            NMFCHK(nmf_solver_check(lane[l], &prev[l], &rl1));
+            if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", first_index + l, 0, prev[l], rl1);
+        }
+    for (int it = 0; it < max_iter;) {
+        int nstep = max_iter - it;
+        if (checks) { const int to_check = iter_check - (it % iter_check); if (to_check < nstep) nstep = to_check; }
+        bool any = false;
+        for (int l = 0; l < n; ++l) if (!done[l]) { NMFCHK(nmf_solver_iterate(lane[l], nstep)); any = true; }
+        if (!any) break;
+        it += nstep;
+        if (checks && (it % iter_check) == 0)
+            for (int l = 0; l < n; ++l) {
+                if (done[l]) continue;
+                double cur = 0.0;
+                NMFCHK(nmf_solver_check(lane[l], &cur, &rl1));
+                if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", first_index + l, it, cur, rl1, (prev[l] - cur) / prev[l]);
+                if (thresh > 0.f && (prev[l] - cur) / prev[l] < (double)thresh) done[l] = 1;   // README.md:51
+                prev[l] = cur;
+            }
+    }
+    for (int l = 0; l < n; ++l) { HIPCHK(hipStreamSynchronize(lane[l]->stream)); }
+    HIPCHK(hipGetLastError());
+    return NMF_OK;
+}
+
+// Measured (tools/restart_bench.py): two lanes overlap one lane's launch gaps and small grids with the other's work
+// (1.3-1.5x on 1024 x 4096 x 64 and 512 x 3445 x 30); more lanes only queue up behind the command processor.  A launch
+// of more than 512 workgroups fills the chip by itself.
+static int auto_lanes(const nmf_solver *s, int n_restarts) {
+    const int per_group = (s->path == NMF_PATH_FUSED) ? fused_cols_per_group(s->Kp) : 128;
+    const long groups = (long)((s->Np + per_group - 1) / per_group) * (s->nsplit_h > 0 ? s->nsplit_h : 1);
+    const int lanes = groups <= 512 ? 2 : 1;
+    return lanes > n_restarts ? n_restarts : lanes;
+}
+
 extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts_in, int *best, double *kl) {
     if (!W || !H || n_restarts < 1 || (!X.mat && !X.mat_d)) { set_err("update_div_restarts: bad arguments"); return NMF_ERR_ARG; }
     nmf_opts o;
@@ -796,25 +844,38 @@ extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_resta
             return NMF_ERR_SHAPE;
         }
     }
-    nmf_solver *s = nullptr;
-    NMFCHK(nmf_solver_create(&s, M, N, K, &o));
-    int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
+    std::vector<nmf_solver *> lane;
+    nmf_solver *s0 = nullptr;
+    NMFCHK(nmf_solver_create(&s0, M, N, K, &o));
+    lane.push_back(s0);
+    int st = X.mat ? nmf_solver_upload(s0, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s0, nullptr, nullptr, X.mat_d);
+    int lanes = o.restart_lanes > 0 ? o.restart_lanes : auto_lanes(s0, n_restarts);
+    if (lanes > n_restarts) lanes = n_restarts;
+    if (o.stream || o.comm) lanes = 1;            // a caller-owned stream or communicator cannot be shared between lanes
+    nmf_opts ol = o;
+    ol.stream = nullptr;
+    for (int l = 1; st == NMF_OK && l < lanes; ++l) {   // further lanes share s0's X
+        nmf_solver *s = new nmf_solver();
+        st = solver_init(s, M, N, K, ol, s0);
+        lane.push_back(s);
+    }
     int best_i = -1;
     double best_kl = 0.0;
-    for (int i = 0; st == NMF_OK && i < n_restarts; ++i) {
-        st = nmf_solver_upload(s, W[i].mat, H[i].mat, nullptr);
-        nmf_result res;
-        memset(&res, 0, sizeof res);
-        if (st == NMF_OK) st = solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, &res, false);
-        double v = 0.0;
-        if (st == NMF_OK) st = nmf_solver_check(s, &v, nullptr);
-        if (st == NMF_OK) st = nmf_solver_download(s, W[i].mat, H[i].mat);
-        if (st == NMF_OK) {
-            if (kl) kl[i] = v;
-            if (best_i < 0 || v < best_kl) { best_i = i; best_kl = v; }
+    for (int base = 0; st == NMF_OK && base < n_restarts; base += lanes) {
+        const int n = (n_restarts - base < lanes) ? (n_restarts - base) : lanes;
+        for (int l = 0; st == NMF_OK && l < n; ++l) st = nmf_solver_upload(lane[l], W[base + l].mat, H[base + l].mat, nullptr);
+        if (st == NMF_OK) st = run_lanes(lane, n, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, base);
+        for (int l = 0; st == NMF_OK && l < n; ++l) {
+            double v = 0.0;
+            st = nmf_solver_check(lane[l], &v, nullptr);
+            if (st == NMF_OK) st = nmf_solver_download(lane[l], W[base + l].mat, H[base + l].mat);
+            if (st == NMF_OK) {
+                if (kl) kl[base + l] = v;
+                if (best_i < 0 || v < best_kl) { best_i = base + l; best_kl = v; }
+            }
         }
     }
-    nmf_solver_destroy(s);
+    for (size_t l = lane.size(); l-- > 0;) nmf_solver_destroy(lane[l]);   // s0 (the owner of X) last
     if (st == NMF_OK && best) *best = best_i;
     return st;
 }

@@ -281,6 +281,13 @@ def test_cfg5_tall_skinny_r512(ng, oracle):
     s.close()
     Wr, Hr, _, _ = oracle.update_div(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]), 0.0, 1, 25)
     print("cfg5 shard K_par=1 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
+    # 200 iterations on the shard shape: KL decreases at every check (SURVEY 8d gate for shapes the CPU cannot iterate)
+    s = ng.Solver(M, ns, K)
+    s.upload(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]))
+    r = s.run(1e-30, 200, 25)
+    s.close()
+    kl = np.asarray(r["kl"])
+    assert r["iterations"] == 200 and len(kl) == 9 and np.all(np.diff(kl) < 0) and np.isfinite(kl).all()
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
     kl0, _ = s.check()
@@ -552,3 +559,25 @@ def test_w_step_row_sums_from_the_streaming_kernel(ng, oracle, M, N, K, nsplit_w
     s.close()
     Wo, Ho, _, _ = oracle.update_div(W1, H1, X, 0.0, 3, 25)
     _cmp(oracle, Wg, Hg, Wo, Ho, 1e-5)
+
+
+@pytest.mark.parametrize("thresh", [0.0, 2e-3])
+def test_restart_lanes_equal_sequential_restarts(ng, oracle, thresh):
+    """nmf_opts.restart_lanes: initialisations iterating side by side on their own streams against one resident X
+    give, bit for bit, what one-after-the-other gives -- with a convergence threshold each lane stops on its own."""
+    M, N, K, R = 512, 1000, 30, 7                       # 7 restarts over 3 lanes: two full waves and a ragged one
+    X, _, _ = oracle.gen_problem(M, N, K, seed=2)
+    rng = np.random.default_rng(9)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    runs = []
+    for lanes in (1, 3, 0):
+        Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+        best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=100, converge_thresh=thresh, iter_check=10, restart_lanes=lanes)
+        runs.append((best, kls, [w.mat.copy() for w in Wm], [h.mat.copy() for h in Hm]))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1]
+        assert all(np.array_equal(a, b) for a, b in zip(r[2], runs[0][2])) and all(np.array_equal(a, b) for a, b in zip(r[3], runs[0][3]))
+    wr, hr, it, _ = oracle.update_div(Ws[2], Hs[2], X, thresh, 100, 10)
+    assert it == 100 or thresh > 0
+    _cmp(oracle, runs[2][2][2], runs[2][3][2], wr, hr, 2e-5)
