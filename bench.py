@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="rehearsal only: gloo lets several ranks share one GPU (with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="rehearsal only: take the N>1 code path (process group, GpuShard, all-reduce) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,9 +109,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.rehearse_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -129,14 +134,14 @@ def main():
 
     comm = None
     shard = None
-    if world > 1 and args.comm == "rccl":
+    if sharded and args.comm == "rccl":
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(ng.Comm.unique_id()), dtype=torch.uint8).clone()
         uid = uid.cuda()
         dist.broadcast(uid, 0)
         comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-    if world > 1 and args.comm == "torch":
+    if sharded and args.comm == "torch":
         # half-step protocol + torch.distributed all-reduce of the (M*K + K)-float partial buffer
         shard = ng.GpuShard(M, Nloc, K, device=local_rank)
         s = shard.solver
@@ -205,10 +210,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.strong_total_N else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
-                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {args.comm})" if world > 1 else " (BASELINE config 3)"),
+                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {args.comm})" if sharded else " (BASELINE config 3)"),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
                        "hipgraph": (not args.no_graph) and shard is None,
-                       "parallelism": f"N-sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"N-sharded x{world}" if sharded else "single GPU"},
             "frac_of_fp32_mfma_peak": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
             "kl_before": kl0, "kl_after": kl1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
