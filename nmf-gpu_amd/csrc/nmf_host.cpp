@@ -98,6 +98,8 @@ struct nmf_solver {
     int nsplit_h = 1, nsplit_w = 1;
     int fast_divide = 0;
     bool x_shared = false;         // X belongs to another solver (update_div_restarts lanes)
+    bool normW_fresh = false;      // normW = max(colsum(W), EPS) of the current W (left by the W-step's apply kernel): the H-step
+                                   // may skip its column-sum launch.  Cleared by everything else that writes W.
     int x_in_range = 0;            // X verified at upload: every entry 0 or in [EPS, 2^60] (FusedArgs::x_in_range)
     unsigned *range_flag = nullptr;
     hipStream_t stream = nullptr;
@@ -126,6 +128,9 @@ struct nmf_solver {
     std::vector<Ev> events;
     double t_setup = 0.0;
 };
+
+// launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
+constexpr int kMaxRowsApplyColsum = 65536;
 
 static int dev_alloc(float **p, size_t count) {
     HIPCHK(hipMalloc((void **)p, count * sizeof(float)));
@@ -265,6 +270,7 @@ static int upload_one(nmf_solver *s, float *dst, int rows_p, int cols_p, const f
         d = s->staging;
     }
     const bool is_x = dst == s->X;
+    if (dst == s->W) s->normW_fresh = false;
     if (is_x) HIPCHK(hipMemsetAsync(s->range_flag, 0, sizeof(unsigned), s->stream));
     HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, is_x ? s->range_flag : nullptr, s->stream));
     if (is_x) {
@@ -348,7 +354,7 @@ static FusedArgs fused_args(nmf_solver *s) {
 static int enqueue_update_h(nmf_solver *s) {
     hipStream_t st = s->stream;
     if (s->path == NMF_PATH_FUSED) {
-        { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }
+        if (!s->normW_fresh) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_h;
         if (s->nsplit_h == 1) {
@@ -413,6 +419,7 @@ static int enqueue_w_partial(nmf_solver *s) {
 
 static int enqueue_w_apply(nmf_solver *s) {
     const size_t mk = (size_t)s->Mp * s->Kp;
+    s->normW_fresh = false;
     PieceScope p(s, NMF_T_APPLY);
     HIPCHK(launch_apply_w(s->W, s->psum, s->psum + mk, s->Mp, s->Kp, s->stream));
     return NMF_OK;
@@ -421,6 +428,7 @@ static int enqueue_w_apply(nmf_solver *s) {
 // cuda/nmf.cu:148-176
 static int enqueue_update_w(nmf_solver *s) {
     hipStream_t st = s->stream;
+    s->normW_fresh = false;
     if (s->comm) {   // N-sharded: one all-reduce of (Mp*Kp + Kp) floats per iteration
         const size_t mk = (size_t)s->Mp * s->Kp;
         NMFCHK(enqueue_w_partial(s));
@@ -440,13 +448,23 @@ static int enqueue_update_w(nmf_solver *s) {
             a.partial = 1; a.vsum_part = s->vsum_part;
             { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
             PieceScope p(s, NMF_T_APPLY);
-            HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, nullptr, s->Mp, s->Np, s->Kp, true, st, s->vsum_part));
+            if (s->Mp <= kMaxRowsApplyColsum) {   // the apply also leaves the next H-step's normaliser
+                HIPCHK(launch_apply_w_colsum(s->W, s->partials, s->nsplit_w, nullptr, s->vsum_part, s->Mp, s->Kp, s->normW, st));
+                s->normW_fresh = true;
+            } else {
+                HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, nullptr, s->Mp, s->Np, s->Kp, true, st, s->vsum_part));
+            }
         } else {
             { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
             a.partial = 1;
             { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
             PieceScope p(s, NMF_T_APPLY);
-            HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, s->normH, s->Mp, s->Np, s->Kp, true, st));
+            if (s->Mp <= kMaxRowsApplyColsum) {
+                HIPCHK(launch_apply_w_colsum(s->W, s->partials, s->nsplit_w, s->normH, nullptr, s->Mp, s->Kp, s->normW, st));
+                s->normW_fresh = true;
+            } else {
+                HIPCHK(launch_apply_partials(s->W, s->partials, s->nsplit_w, s->normH, s->Mp, s->Np, s->Kp, true, st));
+            }
         }
         return NMF_OK;
     }
@@ -530,10 +548,24 @@ static int ensure_graph8(nmf_solver *s) {
     return NMF_OK;
 }
 
+// does the W half-step as this solver runs it end in launch_apply_w_colsum (which leaves normW for the next H-step)?
+static bool w_step_refreshes_normW(const nmf_solver *s) {
+    return s->path == NMF_PATH_FUSED && !s->comm && !s->external_reduce && s->nsplit_w > 1 && s->Mp <= kMaxRowsApplyColsum;
+}
+
 extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
     if (!s || iters < 0) return NMF_ERR_ARG;
     if (s->external_reduce) { set_err("solver is in external-reduce mode"); return NMF_ERR_UNSUPPORTED; }
+    if (iters == 0) return NMF_OK;
     if (s->use_graph && !s->timing) {
+        // A captured iteration starts at the H-step.  Where the W-step's apply hands over normW, the graph holds no
+        // column-sum launch and the very first H-step needs one made here; elsewhere every captured H-step brings its own.
+        const bool lean = w_step_refreshes_normW(s);
+        if (lean && !s->normW_fresh) {
+            HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, s->stream));
+            s->normW_fresh = true;
+        }
+        if (!lean) s->normW_fresh = false;
         int st = ensure_graph(s);
         if (st == NMF_OK) {
             int left = iters;
@@ -651,6 +683,7 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
     HIPCHK(hipEventCreate(&b));
     FusedArgs fa = fused_args(s);
     const size_t mk = (size_t)s->Mp * s->Kp;
+    s->normW_fresh = false;   // the timed pieces overwrite W and H outside the iteration protocol
     // normalisers must be valid before timing an in-place fused step
     HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st));
     HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st));

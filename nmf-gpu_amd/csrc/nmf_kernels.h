@@ -52,6 +52,10 @@ hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream); 
 // norm == nullptr (W-step only): the normaliser is max(sum_s vsum_part[s][k], EPS) instead
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
                                  int Mp, int Np, int Kp, bool wstep, hipStream_t stream, const float *vsum_part = nullptr);
+// W-step apply that also leaves norm_out[k] = max(colsum(W_new)[k], EPS), the next H-step's normaliser (sum_cols + set_epsilon,
+// cuda/nmf.cu:134-135): one 1024-thread workgroup per column of W.  Normaliser from norm or vsum_part as in launch_apply_partials.
+hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, const float *norm, const float *vsum_part,
+                                 int Mp, int Kp, float *norm_out, hipStream_t stream);
 // psum = sum_s partials[s]   (sharded W-step: operand of the all-reduce)
 // vsum_part != nullptr: also psum[count + k] = sum_s vsum_part[s][k], k < Kp (the unclamped row sums of H behind the slab sum)
 hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream,

@@ -66,6 +66,51 @@ hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, co
     return hipGetLastError();
 }
 
+// Sum over a 1024-thread workgroup of per-thread partials (thread t holds rows t, t + 1024, ... of one column): wave shuffle
+// trees, then the 16 wave results in order.  col_sums_kernel and apply_w_colsum_kernel both end in this, so the normaliser
+// of an H-step has the same bits whether it was left by the previous W-step's apply or computed afresh after an upload
+// (resuming from saved factors equals the uninterrupted run, tests/test_gpu_update_div.py::test_resume_...).
+__device__ __forceinline__ float column_total_1024(float partial) {
+    __shared__ float red[16];
+    partial = wave_sum(partial);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = partial;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    return tot;
+}
+
+// One workgroup per column k of W (rows are contiguous): W[:,k] *= (sum_s P[s][:,k]) / n_k, and the column sum of the new
+// values, reduced in a fixed order (per-thread strided partial -> wave shuffle tree -> 16 waves), clamped, goes to norm_out[k].
+__global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict__ W, const float *__restrict__ P, int nsplit,
+                                                              const float *__restrict__ nrm, const float *__restrict__ vsum_part,
+                                                              int Mp, int Kp, float *__restrict__ norm_out) {
+    const int k = blockIdx.x;
+    float n;
+    if (vsum_part) {
+        n = vsum_part[k];
+        for (int sp = 1; sp < nsplit; ++sp) n += vsum_part[(size_t)sp * Kp + k];
+        n = clamp_eps(n);
+    } else n = nrm[k];
+    const size_t count = (size_t)Mp * Kp, col = (size_t)k * Mp;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < Mp; i += 1024) {
+        float s = P[col + i];
+        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + col + i];
+        const float w = __fmul_rn(W[col + i], s / n);   // _rn: the product that is stored is the one that is summed (no fma contraction)
+        W[col + i] = w;
+        acc = __fadd_rn(acc, w);
+    }
+    const float tot = column_total_1024(acc);
+    if (threadIdx.x == 0) norm_out[k] = clamp_eps(tot);
+}
+hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, const float *norm, const float *vsum_part, int Mp, int Kp,
+                                 float *norm_out, hipStream_t stream) {
+    if ((!norm && !vsum_part) || !norm_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(apply_w_colsum_kernel, dim3(Kp), dim3(1024), 0, stream, W, partials, nsplit, norm, vsum_part, Mp, Kp, norm_out);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ out, const float *__restrict__ P, int nsplit, size_t count,
                                                            const float *__restrict__ vsum_part, int Kp) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
@@ -138,21 +183,15 @@ hipError_t launch_kl_reduce(const float *x, const float *y, size_t n, double *pa
 // Normalisers (sum_cols / sum_rows + set_epsilon, cuda/nmf.cu:134-135, 164-165)
 // wave64 shuffle tree + LDS across the 4 waves; fixed summation order -> reproducible.
 // =====================================================================================
-__global__ __launch_bounds__(256) void col_sums_kernel(const float *__restrict__ A, int rows, long ld, float *__restrict__ out, int clamp) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void col_sums_kernel(const float *__restrict__ A, int rows, long ld, float *__restrict__ out, int clamp) {
     const float *__restrict__ a = A + (size_t)blockIdx.x * ld;
     float s = 0.f;
-    for (int i = threadIdx.x; i < rows; i += 256) s += a[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = (red[0] + red[1]) + (red[2] + red[3]);
-        out[blockIdx.x] = clamp ? clamp_eps(tot) : tot;
-    }
+    for (int i = threadIdx.x; i < rows; i += 1024) s += a[i];
+    const float tot = column_total_1024(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = clamp ? clamp_eps(tot) : tot;
 }
 hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream) {
-    hipLaunchKernelGGL(col_sums_kernel, dim3(cols), dim3(256), 0, stream, A, rows, ld, out, clamp ? 1 : 0);
+    hipLaunchKernelGGL(col_sums_kernel, dim3(cols), dim3(1024), 0, stream, A, rows, ld, out, clamp ? 1 : 0);
     return hipGetLastError();
 }
 
