@@ -421,7 +421,12 @@ static int enqueue_w_apply(nmf_solver *s) {
     const size_t mk = (size_t)s->Mp * s->Kp;
     s->normW_fresh = false;
     PieceScope p(s, NMF_T_APPLY);
-    HIPCHK(launch_apply_w(s->W, s->psum, s->psum + mk, s->Mp, s->Kp, s->stream));
+    if (s->Mp <= kMaxRowsApplyColsum) {   // W *= psum / max(hsum, EPS), and the next H-step's normaliser with it (every rank: same bits)
+        HIPCHK(launch_apply_w_colsum(s->W, s->psum, 1, nullptr, s->psum + mk, s->Mp, s->Kp, s->normW, s->stream));
+        s->normW_fresh = true;
+    } else {
+        HIPCHK(launch_apply_w(s->W, s->psum, s->psum + mk, s->Mp, s->Kp, s->stream));
+    }
     return NMF_OK;
 }
 
@@ -550,7 +555,8 @@ static int ensure_graph8(nmf_solver *s) {
 
 // does the W half-step as this solver runs it end in launch_apply_w_colsum (which leaves normW for the next H-step)?
 static bool w_step_refreshes_normW(const nmf_solver *s) {
-    return s->path == NMF_PATH_FUSED && !s->comm && !s->external_reduce && s->nsplit_w > 1 && s->Mp <= kMaxRowsApplyColsum;
+    if (s->Mp > kMaxRowsApplyColsum) return false;
+    return s->comm ? true : (s->path == NMF_PATH_FUSED && s->nsplit_w > 1);
 }
 
 extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
