@@ -24,9 +24,9 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz
 # HBM bytes per fused_step launch at cfg3 from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
 # profiles/r01_pmc_summary.md).  bench.py cannot collect PMC itself; other shapes report null.
-PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.369e9, "W": 1.210e9}}
+PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.368e9, "W": 1.209e9}}
 # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of the same launches, same PMC runs
-PMC_MFMA_BUSY = {(4096, 65536, 256): {"H": 0.908, "W": 0.915}}
+PMC_MFMA_BUSY = {(4096, 65536, 256): {"H": 0.912, "W": 0.917}}
 
 
 def synth(seed, rows, cols):
