@@ -41,8 +41,9 @@ def synth(seed, rows, cols):
 
 
 def cpu_baseline(M, Nfull, K, budget_s=20.0):
-    """The oracle (`port`: our own C/OpenMP restatement; the reference has no CPU path) timed on
-    this host's cores on a bounded sample: the first `Ns` columns of the same workload."""
+    """The oracle (`port`: our own C/OpenMP restatement; the reference has no CPU path) timed on this host's cores on
+    a bounded sample: the first `Ns` columns of the same workload, through oracle_fast_update_div (the oracle's
+    arithmetic arranged around its fastest SGEMM kernel, oracle/nmf_oracle_fast.c)."""
     import oracle
     Ns = min(Nfull, 8192)
     X = synth(1000, M, Ns); W = synth(0, M, K); H = synth(2000, K, Ns)
@@ -52,19 +53,17 @@ def cpu_baseline(M, Nfull, K, budget_s=20.0):
     except Exception:
         native = False
     cores = oracle.num_threads(native)
-    oracle.update_div(W, H, X, 0.0, 1, 0, native=native)           # warm-up (page faults, thread pool)
-    iters, t = 0, 0.0
     t0 = time.perf_counter()
-    while True:
-        oracle.update_div(W, H, X, 0.0, 1, 0, native=native)
-        iters += 1
-        t = time.perf_counter() - t0
-        if t > budget_s or iters >= 20:
-            break
+    oracle.update_div_fast(W, H, X, 1, native=native)               # warm-up (page faults, thread pool) and a time estimate
+    t_one = time.perf_counter() - t0
+    iters = int(max(3, min(200, budget_s / max(t_one, 1e-3))))
+    t0 = time.perf_counter()
+    oracle.update_div_fast(W, H, X, iters, native=native)
+    t = time.perf_counter() - t0
     flops = 8.0 * M * Ns * K * iters
     tf = flops / t / 1e12
     return {"value": tf, "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"oracle spec-mode update_div, M={M} K={K}, first {Ns} of {Nfull} columns, {iters} iterations in {t:.1f} s"
+            "sample": f"oracle spec-mode update_div (oracle_fast_update_div), M={M} K={K}, first {Ns} of {Nfull} columns, {iters} iterations in {t:.1f} s"
                       f" ({'-march=native' if native else 'avx2'} build); = {tf * 1e12 / (8.0 * M * Nfull * K):.4f} full-size iterations/s",
             "iterations_per_s_full_size": tf * 1e12 / (8.0 * M * Nfull * K)}
 
@@ -80,7 +79,7 @@ def main():
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
                     help="N>1: all-reduce through torch.distributed (default) or in-library RCCL inside the hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--strong-total-N", type=int, default=0,
                     help="strong scaling instead of the default weak scaling: total column count split over the ranks "
                          "(BASELINE config 4: --strong-total-N 262144)")

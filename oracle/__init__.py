@@ -88,6 +88,8 @@ def _bind(path: str):
         f = getattr(lib, name)
         f.restype = None
         f.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int]
+    lib.oracle_fast_update_div.restype = C.c_int
+    lib.oracle_fast_update_div.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.oracle_rng_seed.restype = None
     lib.oracle_rng_seed.argtypes = [C.c_void_p, C.c_uint32]
     lib.oracle_rng_fill_f32.restype = None
@@ -108,8 +110,8 @@ def lib(native: bool = False):
         return _lib_native
     if _lib is None:
         path = os.path.join(_HERE, "libnmf_oracle.so")
-        src = os.path.join(_HERE, "nmf_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(_HERE, f) for f in ("nmf_oracle.c", "nmf_oracle_fast.c", "nmf_oracle.h")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
             build()
         _lib = _bind(path)
     return _lib
@@ -161,6 +163,17 @@ def update_div(W, H, X, thresh: float = 0.0, max_iter: int = 200, iter_check: in
                                        C.byref(nkl))
     return (w.reshape((M, K), order="F"), h.reshape((K, N), order="F"), it,
             np.array(kl[: min(nkl.value, cap)]))
+
+
+def update_div_fast(W, H, X, iters: int = 1, native: bool = False):
+    """`iters` spec-mode iterations through the register-tiled baseline kernels (nmf_oracle_fast.c): what bench.py
+    times as the CPU baseline.  Returns (W, H) as F-ordered copies."""
+    M, K = W.shape
+    N = H.shape[1]
+    w, h, x = _flat(W).copy(), _flat(H).copy(), _flat(X)
+    if lib(native).oracle_fast_update_div(w, h, x, M, N, K, iters) != 0:
+        raise MemoryError("oracle_fast_update_div: scratch allocation failed")
+    return w.reshape((M, K), order="F"), h.reshape((K, N), order="F")
 
 
 def update_h(W, H, X, mode: int = MODE_SPEC):

@@ -81,6 +81,11 @@ int    oracle_update_div(float *W, float *H, const float *X, int M, int N, int K
 int    oracle_read_bin(const char *path, uint32_t *rows, uint32_t *cols, float **data);
 int    oracle_write_bin(const char *path, uint32_t rows, uint32_t cols, const float *data);
 
+/* The timed CPU baseline (nmf_oracle_fast.c): `iters` spec-mode iterations with register-tiled SGEMM micro-kernels.
+ * Same math, different summation order than oracle_update_div -- checked against it by tolerance, never used as
+ * the parity checker.  Returns 0, -1 if scratch cannot be allocated. */
+int    oracle_fast_update_div(float *W, float *H, const float *X, int M, int N, int K, int iters);
+
 int    oracle_num_threads(void);
 void   oracle_set_num_threads(int n);
 

@@ -70,3 +70,15 @@ def test_bin_roundtrip(oracle, tmp_path):
         raw = f.read()
     assert raw[:8] == np.array([13, 7], dtype=np.uint32).tobytes() and len(raw) == 8 + 13 * 7 * 4
     assert np.array_equal(oracle.read_bin(p), A)
+
+
+def test_fast_baseline_path_matches_the_oracle(oracle):
+    """bench.py's cpu_baseline times oracle_fast_update_div (same math around the fastest SGEMM kernel, two explicit
+    transposes): it must agree with the pinned oracle loop to fp32 summation-order noise, ragged shapes included."""
+    for (M, N, K, iters) in ((100, 70, 17, 3), (257, 130, 64, 5), (33, 1, 1, 2), (64, 96, 32, 10)):
+        X, W, H = oracle.gen_problem(M, N, K, seed=3)
+        X[0, 0] = 0.0                                       # clamped to EPS on the private copy, not in the caller's X
+        Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, iters, 0)
+        Wf, Hf = oracle.update_div_fast(W, H, X, iters)
+        assert oracle.relF(Wf, Wr) < 5e-6 and oracle.relF(Hf, Hr) < 5e-6
+        assert X[0, 0] == 0.0
