@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the built artefacts are git-ignored: a fresh checkout builds them (hipcc cross-compiles gfx950 without a GPU)
+    pkg = os.path.join(ROOT, "nmf-gpu_amd")
+    if not (os.path.exists(os.path.join(pkg, "libnmf_mi355x.so")) and os.path.exists(os.path.join(pkg, "nmf"))):
+        import subprocess
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(pkg, "csrc"), "all"], check=True)
 
 
 def _has_gpu() -> bool:
