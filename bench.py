@@ -99,6 +99,7 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
     import torch
     import nmf_gpu_amd as ng
     ng.lib()   # fail loudly if the HIP library is missing
