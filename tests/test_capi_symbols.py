@@ -51,6 +51,28 @@ def test_matrix_struct_layout(ng):
     assert C.sizeof(_matrix) == 24 and _matrix.mat.offset == 0 and _matrix.mat_d.offset == 8 and _matrix.dim.offset == 16
 
 
+def test_opts_and_result_struct_layouts_match_the_header(ng, tmp_path):
+    """the ctypes mirrors of nmf_opts / nmf_result against what a C compiler makes of include/nmf_mi355x.h"""
+    from nmf_gpu_amd.api import _opts, _result
+    src = tmp_path / "layout.c"
+    fields_o = [f[0] for f in _opts._fields_]
+    fields_r = [f[0] for f in _result._fields_]
+    body = "".join(f'printf("o {f} %zu\\n", offsetof(nmf_opts, {f}));' for f in fields_o)
+    body += "".join(f'printf("r {f} %zu\\n", offsetof(nmf_result, {f}));' for f in fields_r)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nmf_mi355x.h"\nint main(void){'
+                   'printf("so %zu\\nsr %zu\\n", sizeof(nmf_opts), sizeof(nmf_result));' + body + "return 0;}")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)   # plain C: no HIP, no torch
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.startswith(("o ", "r "))}
+    sizes = {l.split()[0]: int(l.split()[1]) for l in out if l.startswith(("so ", "sr "))}
+    assert sizes == {"so": C.sizeof(_opts), "sr": C.sizeof(_result)}
+    for f in fields_o:
+        assert got[("o", f)] == getattr(_opts, f).offset, f
+    for f in fields_r:
+        assert got[("r", f)] == getattr(_result, f).offset, f
+
+
 def test_read_write_matrix_format(ng, tmp_path):
     """uint32 rows, uint32 cols, float32 column-major, no padding (cuda/nmf.cu:194-204, 239-249)"""
     A = np.asfortranarray(np.arange(15, dtype=np.float32).reshape(3, 5))
