@@ -581,3 +581,33 @@ def test_restart_lanes_equal_sequential_restarts(ng, oracle, thresh):
     wr, hr, it, _ = oracle.update_div(Ws[2], Hs[2], X, thresh, 100, 10)
     assert it == 100 or thresh > 0
     _cmp(oracle, runs[2][2][2], runs[2][3][2], wr, hr, 2e-5)
+
+
+@pytest.mark.parametrize("variant", ["1", "3"])
+def test_32_column_kernel_family_via_env_override(oracle, variant, tmp_path):
+    """NMF_FUSED_VARIANT=3 runs the 32-column kernel (production only for K <= 32) and =1 the first-generation kernel
+    (the 64-bit-addressing fallback for M*K >= 2^31, with its own KL check kernel) at a K where the 16-column kernel
+    would normally serve: both must meet the same parity bar.  The override is read once per process, hence a child."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, oracle, nmf_gpu_amd as ng
+M, N, K = 200, 330, 64
+X, W, H = oracle.gen_problem(M, N, K, seed=12)
+s = ng.Solver(M, N, K, path=ng.PATH_FUSED)
+s.upload(W, H, X)
+kl0, _ = s.check()
+s.iterate(12)
+kl1, rl1 = s.check()
+Wg, Hg = s.download()
+s.close()
+Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 12, 25)
+klr = oracle.kl_div(oracle.clamp(X), np.maximum(oracle.sgemm("nn", Wr, Hr), oracle.EPS))
+assert oracle.relF(Wg, Wr) < 1e-5 and oracle.relF(Hg, Hr) < 1e-5, (oracle.relF(Wg, Wr), oracle.relF(Hg, Hr))
+assert abs(kl1 - klr) <= 1e-4 * abs(klr) and kl1 < kl0
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NMF_FUSED_VARIANT=variant), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
