@@ -5,6 +5,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN, ROOT
 from test_oracle_golden import REF_MD5
@@ -51,3 +52,34 @@ def test_compare_is_test_output_with_a_tolerance(oracle, tmp_path):
     assert r.returncode != 0 and "cannot open" in r.stderr
     # the reference's golden pair against itself, and against each other's inputs
     assert _run("compare", os.path.join(GOLDEN, "Wtest.bin"), os.path.join(GOLDEN, "Wtest.bin")).returncode == 0
+
+
+def _build_reference_main(tmp_path):
+    exe = tmp_path / "bin" / "nmf_ref_main"
+    exe.parent.mkdir()
+    pkg = os.path.join(ROOT, "nmf-gpu_amd")
+    subprocess.run(["g++", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "reference_main.cpp"),
+                    "-L", pkg, "-lnmf_mi355x", f"-Wl,-rpath,{pkg}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_reference_main_rebound_compiles_and_links(tmp_path):
+    """the reference's main() with update_div in place of run_async builds with the host
+    compiler against the public header and the shared library alone (no HIP, no torch)."""
+    exe = _build_reference_main(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, cwd=exe.parent, timeout=60)   # no ../X.bin here
+    assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_reference_main_rebound_runs_the_reference_workflow(oracle, tmp_path):
+    """matrix_export.py -> ./nmf -> test_output.sh with the rebound main: ../X.bin ../W.bin ../H.bin in, 200 iterations,
+    ../Wout.bin ../Hout.bin out (cuda/nmf.cu:30-51), checked against the oracle run on the same files."""
+    exe = _build_reference_main(tmp_path)
+    assert _run("generate", "--M", "512", "--N", "350", "--K", "64", cwd=tmp_path).returncode == 0
+    r = subprocess.run([str(exe)], capture_output=True, text=True, cwd=exe.parent, timeout=300)
+    assert r.returncode == 0, r.stderr
+    X, W, H = (oracle.read_bin(str(tmp_path / f)) for f in ("X.bin", "W.bin", "H.bin"))
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
+    assert oracle.relF(oracle.read_bin(str(tmp_path / "Wout.bin")), Wr) < 1e-4
+    assert oracle.relF(oracle.read_bin(str(tmp_path / "Hout.bin")), Hr) < 1e-4
