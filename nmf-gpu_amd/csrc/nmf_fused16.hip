@@ -17,12 +17,14 @@ namespace nmf {
 // k index of product-1 step s in lane group kq: 64 (s >> 4) + 16 kq + (s & 15): per-lane contiguous runs
 // of 16 (16-B loads of the owned factor) and, with 33-float LDS rows, 32 distinct banks per half-wave.
 // CHECK = true turns the kernel into the KL / rel-L1 check (product 1 only), see check_kernel.
+// GEMM = true (H-step orientation only) keeps product 1 alone and stores it: C = W * H for K <= 512, the reference's
+// matrix_multiply (cuda/matrix.cu:97-105) on the W*H shape at the rate of the fused loop (a.U_out = C, ld = Mp; a.X unused).
 // =====================================================================================
 typedef const __attribute__((address_space(1))) char *global_bytes;
 #define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int kXt16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
 
-template <int NB, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1>
+template <int NB, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1, bool GEMM = false>
 __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, double *__restrict__ chk_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 64 * NB;
@@ -142,11 +144,13 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         set_chunk(c_begin);
 #pragma unroll
         for (int q = 0; q < NST; ++q) stage_load_one(q);
+        if (!GEMM) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) x_load_one(i);
+            for (int i = 0; i < 2; ++i) x_load_one(i);
+        }
 #pragma unroll
         for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, w);
-        x_relayout();
+        if (!GEMM) x_relayout();
         __syncthreads();
         for (int ch = c_begin; ch < c_end; ++ch) {
             const int par = (ch - c_begin) & 1;
@@ -178,7 +182,19 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     const int en = e + D;
                     ar[e % D] = lds_ld(b1 + (64 * ((en >> 1) >> 4) + ((en >> 1) & 15)) * kLdv + 16 * (en & 1));
                 }
-                if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
+                if (GEMM) {
+                    // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
+                    // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: exactly 4*NST)
+                    constexpr int GL = (E1 / 2) / (NST + 1);
+                    if (e >= GL && e % GL == 0 && e / GL - 1 < NST) {
+                        stage_load_one(e / GL - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (e >= E1 / 2 && (e - E1 / 2) % 2 == 0 && (e - E1 / 2) / 2 < 4 * NST) {
+                        stage_store_one(vn, (e - E1 / 2) / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
                     const int l = e / G - 1;
                     if (l < 2) x_load_one(l); else stage_load_one(l - 2);
                     __builtin_amdgcn_sched_barrier(0);
@@ -186,6 +202,15 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             }
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
+            if (GEMM) {   // lane holds S(p0 + 16 T + 4 kq + r, q0 + j): two 16-B stores per chunk, 64 B contiguous per column and half
+                if (active) {
+                    float *c = a.U_out + (size_t)(q0 + j) * (size_t)a.Mp + (size_t)ch * 32 + 4 * kq;
+                    *reinterpret_cast<f32x4 *>(c) = s0;
+                    *reinterpret_cast<f32x4 *>(c + 16) = s1;
+                }
+                __syncthreads();
+                continue;
+            }
             if (CHECK) {
                 float fkl = 0.f, fd = 0.f, fx = 0.f;
 #pragma unroll
@@ -235,6 +260,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             __syncthreads();
         }
     }
+    if (GEMM) return;
     if (WSTEP && PARTIAL) {
         if (vsum_on) {
 #pragma unroll
@@ -322,6 +348,38 @@ static hipError_t launch_check_k16(const float *W, const float *H, const float *
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
     return hipGetLastError();
+}
+
+template <int NB, int OCC>
+static hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream) {
+    FusedArgs a;
+    a.W = A; a.H = B; a.X = nullptr; a.U_out = C; a.partials = nullptr; a.norm = nullptr;
+    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
+    const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
+    hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, (double *)nullptr);
+    return hipGetLastError();
+}
+
+// C(Mp x Np) = A(Mp x Kp) * B(Kp x Np), all contiguous column-major; Mp % 32 == 0, Np % 16 == 0, Kp in {64, 128, 256, 320..512 step 64}
+hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream) {
+    if ((Mp & 31) || (Np & 15) || Np < 16 || (Kp % 64) || (size_t)Mp * (size_t)Kp >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    switch (Kp / 64) {
+        case 1: return launch_gemm_k16<1, 2>(A, B, C, Mp, Np, Kp, stream);
+        case 2: return launch_gemm_k16<2, 2>(A, B, C, Mp, Np, Kp, stream);
+        case 4: return launch_gemm_k16<4, 2>(A, B, C, Mp, Np, Kp, stream);
+        case 5: return launch_gemm_k16<5, 1>(A, B, C, Mp, Np, Kp, stream);
+        case 6: return launch_gemm_k16<6, 1>(A, B, C, Mp, Np, Kp, stream);
+        case 7: return launch_gemm_k16<7, 1>(A, B, C, Mp, Np, Kp, stream);
+        case 8: return launch_gemm_k16<8, 1>(A, B, C, Mp, Np, Kp, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+bool gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc) {
+    const int nb = k / 64;
+    return (m % 32 == 0) && (n % 16 == 0) && n >= 16 && (k % 64 == 0) && (nb == 1 || nb == 2 || (nb >= 4 && nb <= 8)) && lda == m && ldb == k && ldc == m &&
+           (size_t)m * (size_t)k < ((size_t)1 << 31);
 }
 
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream) {

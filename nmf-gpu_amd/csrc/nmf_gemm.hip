@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(int m, int n, int k_tota
 hipError_t launch_gemm(GemmKind kind, int m, int n, int k, const float *A, long lda, const float *B, long ldb, float *C, long ldc,
                        hipStream_t stream, float *workspace, size_t workspace_floats) {
     if (m <= 0 || n <= 0 || k <= 0) return hipErrorInvalidValue;
+    // the NMF product W * H (tall A, K <= 512, everything contiguous): the fused kernels' product-1 engine, B in registers
+    static const bool generic_only = getenv("NMF_GEMM_GENERIC") != nullptr;   // A/B switch (tools/gemm_bench.py)
+    if (!generic_only && kind == GEMM_NN && m >= 1024 && gemm_nn16_eligible(m, n, k, lda, ldb, ldc) &&
+        (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) % 16 == 0)
+        return launch_gemm_nn16(A, B, C, m, n, k, stream);
     const int tiles = ((m + 127) / 128) * ((n + 127) / 128);
     // small output, long reduction (Z*H' of the W-step): split K over workgroups into slabs, then sum them in order
     int nsplit = 1;

@@ -40,6 +40,9 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
 // the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 64 <= Kp <= 512; nmf_fused32.hip: Kp <= 256)
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
+// C = A * B through product 1 of the 16-column kernel (the W*H shape: tall A, K <= 512), see nmf_fused16.hip
+bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
+hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe

@@ -24,7 +24,8 @@ def _tol64(k):
 
 GEMM_SHAPES = [(128, 128, 64), (1024, 4096, 64), (4096, 352, 128), (70, 45, 33), (1, 1, 1), (129, 257, 17),
                (256, 96, 300), (300, 100, 9000),   # takes the split-K path of A*B'
-               (256, 384, 144), (128, 128, 16), (384, 256, 4112)]   # tile-aligned: the 16-B-load fast path (+ split-K)
+               (256, 384, 144), (128, 128, 16), (384, 256, 4112),   # tile-aligned: the 16-B-load fast path (+ split-K)
+               (2048, 80, 320), (1024, 48, 512), (4096, 1040, 256)]  # tall A, K <= 512: A*B through the 16-column kernel's product 1
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -54,6 +55,20 @@ def test_matrix_multiply_identity_asymmetric(ng):
     c3 = ng.Matrix(rows=n, cols=80).to_device()
     ng.matrix_multiply_ABt(_dev(ng, I), _dev(ng, Bt), c3)
     assert np.array_equal(c3.from_device().mat, B)
+
+
+@pytest.mark.parametrize("k", [64, 128, 256, 384, 512])
+def test_matrix_multiply_wh_shape_exact_lane_map(ng, k):
+    """The W*H-shaped product (tall A, K <= 512) runs on the 16-column kernel's product 1 with B held in registers:
+    with B a 0/1 selection matrix every output column must be an exact copy of one column of A."""
+    m, n = 1024, 80
+    A = np.asfortranarray((np.arange(m * k, dtype=np.float32).reshape(m, k) % 8191) * np.float32(0.25) + 1.0)
+    sel = (np.arange(n) * 37 + 5) % k
+    B = np.zeros((k, n), dtype=np.float32, order="F")
+    B[sel, np.arange(n)] = 1.0
+    c = ng.Matrix(rows=m, cols=n).to_device()
+    ng.matrix_multiply(_dev(ng, A), _dev(ng, B), c)
+    assert np.array_equal(c.from_device().mat, A[:, sel])
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)

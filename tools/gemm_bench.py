@@ -2,8 +2,9 @@ import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nmf_gpu_amd as ng
 hip = C.CDLL("libamdhip64.so")
-def bench(fn, reps=5):
-    fn(); hip.hipDeviceSynchronize()
+def bench(fn, reps=10):
+    for _ in range(4): fn()          # clocks ramp over the first few launches
+    hip.hipDeviceSynchronize()
     t0=time.perf_counter()
     for _ in range(reps): fn()
     hip.hipDeviceSynchronize()
