@@ -106,6 +106,9 @@ typedef struct {
     int   restart_lanes;    /* update_div_restarts only: how many initialisations iterate concurrently, each on its own stream
                              * against the one resident X (small problems fill a fraction of the 256 CUs per launch);
                              * 0 = automatic (two lanes unless one launch already fills the chip), 1 = one after the other */
+    int   split_kernel;     /* which fused kernel family: 0 = automatic; 1 = the split kernel (four waves per 16 owned columns,
+                             * normalisers summed in-stream, two to four launches per iteration: problems that do not fill
+                             * the chip, K <= 128); -1 = never (the 64-column kernel of the large configurations) */
 } nmf_opts;
 
 #define NMF_MAX_KL 64
@@ -206,6 +209,18 @@ int  nmf_solver_partial_buffer(nmf_solver *s, float **dev_ptr, size_t *count);
 /* make the solver use a caller-owned device buffer of `count` floats (>= the count reported above) as
  * its partial buffer, e.g. the storage of a torch tensor that torch.distributed will all-reduce */
 int  nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size_t count);
+/* B independent (W, H) pairs against one X in every launch (multi-restart NMF, paper section 3.2; the restart index is a
+ * grid dimension of the split kernel, K <= 128).  Pair b is addressed by the *_pair calls; upload / download / check
+ * without a pair index act on pair 0.  `flags` (batch ints, host) freezes pairs whose flag is 0: they are skipped by
+ * every later iterate (a converged restart stops exactly where a sequential update_div would). */
+int  nmf_solver_create_batched(nmf_solver **s, int M, int N, int K, int batch, const nmf_opts *opts);
+int  nmf_solver_batch(const nmf_solver *s);
+int  nmf_solver_upload_pair(nmf_solver *s, int b, const float *W, const float *H);
+int  nmf_solver_download_pair(nmf_solver *s, int b, float *W, float *H);
+int  nmf_solver_check_pair(nmf_solver *s, int b, double *kl, double *rel_l1);
+int  nmf_solver_set_active(nmf_solver *s, const int *flags);
+/* 1 if this solver runs the split kernel (see nmf_opts.split_kernel) */
+int  nmf_solver_uses_split_kernel(const nmf_solver *s);
 int  nmf_solver_path(const nmf_solver *s);
 void *nmf_solver_stream(nmf_solver *s);
 

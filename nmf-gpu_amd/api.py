@@ -49,7 +49,7 @@ class _opts(C.Structure):
     _fields_ = [("converge_thresh", C.c_float), ("max_iter", C.c_int), ("iter_check", C.c_int),
                 ("verbose", C.c_int), ("path", C.c_int), ("use_graph", C.c_int), ("device", C.c_int),
                 ("stream", C.c_void_p), ("comm", C.c_void_p), ("nsplit_h", C.c_int), ("nsplit_w", C.c_int),
-                ("fast_divide", C.c_int), ("restart_lanes", C.c_int)]
+                ("fast_divide", C.c_int), ("restart_lanes", C.c_int), ("split_kernel", C.c_int)]
 
 
 class _result(C.Structure):
@@ -103,6 +103,13 @@ _SIGS = [
     ("nmf_solver_w_apply", C.c_int, [C.c_void_p]),
     ("nmf_solver_partial_buffer", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("nmf_solver_set_partial_buffer", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("nmf_solver_create_batched", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_opts)]),
+    ("nmf_solver_batch", C.c_int, [C.c_void_p]),
+    ("nmf_solver_upload_pair", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("nmf_solver_download_pair", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("nmf_solver_check_pair", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("nmf_solver_set_active", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    ("nmf_solver_uses_split_kernel", C.c_int, [C.c_void_p]),
     ("nmf_solver_path", C.c_int, [C.c_void_p]),
     ("nmf_solver_stream", C.c_void_p, [C.c_void_p]),
     ("nmf_comm_get_unique_id", C.c_int, [C.c_char_p]),
@@ -216,6 +223,25 @@ def _as_matrix(a) -> Matrix:
     return a if isinstance(a, Matrix) else Matrix(a)
 
 
+def _inout(a, who: str):
+    """An in/out factor (W or H of update_div): a ``Matrix`` is updated through its own buffer; a numpy array is copied
+    into a column-major ``Matrix`` for the call and the result is copied back into the caller's array by ``_copy_back``;
+    anything else cannot be updated in place and is refused."""
+    if isinstance(a, Matrix):
+        return a, None
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{who} is updated in place: pass an nmf Matrix or a numpy array, not {type(a).__name__}")
+    if not a.flags.writeable:
+        raise TypeError(f"{who} is updated in place: the array is read-only")
+    return Matrix(a), a
+
+
+def _copy_back(pairs):
+    for m, orig in pairs:
+        if orig is not None:
+            np.copyto(orig, m.mat, casting="same_kind")
+
+
 def read_matrix(path: str) -> Matrix:
     """cuda/nmf.cu:188-218 (header uint32 rows, cols; column-major float32 payload)."""
     m = _matrix()
@@ -256,31 +282,35 @@ def _result_dict(r: _result) -> dict:
 def update_div(W, H, X, CONVERGE_THRESH: float = 0.0, max_iter: int = 200, t=None, verbose: int = 0) -> None:
     """The documented drop-in (README.md:40-54): W, H updated in place (their ``.mat``),
     ``t`` an optional list/array of >= 10 doubles that receives the timers."""
-    W, H, X = _as_matrix(W), _as_matrix(H), _as_matrix(X)
+    (W, w0), (H, h0), X = _inout(W, "W"), _inout(H, "H"), _as_matrix(X)
     if H.rows != W.cols or X.rows != W.rows or X.cols != H.cols:
         # the C entry point exit()s on a shape error like the reference; raise here instead
         raise NmfError(2, "dimensions do not agree")
     tt = (C.c_double * 10)() if t is not None else None
     lib().update_div(W._c, H._c, X._c, CONVERGE_THRESH, max_iter, tt, verbose)
+    _copy_back(((W, w0), (H, h0)))
     if t is not None:
         for i in range(10):
             t[i] = tt[i]
 
 
 def update_div_ex(W, H, X, **opts) -> dict:
-    """Status-returning variant; options as in ``nmf_opts``.  Returns the result dict."""
-    W, H, X = _as_matrix(W), _as_matrix(H), _as_matrix(X)
+    """Status-returning variant; options as in ``nmf_opts``.  W, H (``Matrix`` or numpy arrays) are updated in place.
+    Returns the result dict."""
+    (W, w0), (H, h0), X = _inout(W, "W"), _inout(H, "H"), _as_matrix(X)
     o = _make_opts(**opts)
     r = _result()
     _chk(lib().update_div_ex(W._c, H._c, X._c, C.byref(o), C.byref(r)))
+    _copy_back(((W, w0), (H, h0)))
     return _result_dict(r)
 
 
 def update_div_restarts(Ws, Hs, X, **opts):
     """Paper section 3.2: run every (W, H) initialisation, keep X resident; returns (best_index, [kl...]).
     All pairs are updated in place."""
-    Ws = [_as_matrix(w) for w in Ws]
-    Hs = [_as_matrix(h) for h in Hs]
+    wp = [_inout(w, "W") for w in Ws]
+    hp = [_inout(h, "H") for h in Hs]
+    Ws, Hs = [m for m, _ in wp], [m for m, _ in hp]
     X = _as_matrix(X)
     n = len(Ws)
     if n == 0 or len(Hs) != n:
@@ -291,6 +321,7 @@ def update_div_restarts(Ws, Hs, X, **opts):
     best = C.c_int(-1)
     kl = (C.c_double * n)()
     _chk(lib().update_div_restarts(wa, ha, n, X._c, C.byref(o), C.byref(best), kl))
+    _copy_back(wp + hp)
     return best.value, [kl[i] for i in range(n)]
 
 
@@ -370,14 +401,14 @@ class Solver:
 
     def __init__(self, M: int, N: int, K: int, *, path: int = PATH_AUTO, use_graph: bool = True,
                  device: int = -1, stream: Optional[int] = None, comm: Optional[Comm] = None,
-                 nsplit_h: int = 0, nsplit_w: int = 0, fast_divide: int = 0):
-        self.M, self.N, self.K = M, N, K
+                 nsplit_h: int = 0, nsplit_w: int = 0, fast_divide: int = 0, split_kernel: int = 0, batch: int = 1):
+        self.M, self.N, self.K, self.batch = M, N, K, batch
         o = _make_opts(path=path, use_graph=int(use_graph), device=device, stream=stream,
                        comm=(comm._h.value if comm is not None else None), nsplit_h=nsplit_h, nsplit_w=nsplit_w,
-                       fast_divide=int(fast_divide))
+                       fast_divide=int(fast_divide), split_kernel=int(split_kernel))
         self._h = C.c_void_p()
         self._comm = comm
-        _chk(lib().nmf_solver_create(C.byref(self._h), M, N, K, C.byref(o)))
+        _chk(lib().nmf_solver_create_batched(C.byref(self._h), M, N, K, batch, C.byref(o)))
 
     def close(self):
         if self._h:
@@ -416,6 +447,31 @@ class Solver:
         H = np.empty((self.K, self.N), dtype=np.float32, order="F")
         _chk(lib().nmf_solver_download(self._h, W.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
         return W, H
+
+    @property
+    def uses_split_kernel(self) -> bool:
+        return bool(lib().nmf_solver_uses_split_kernel(self._h))
+
+    # pair b of a batched solver (multi-restart: B (W, H) pairs against one X per launch)
+    def upload_pair(self, b: int, W=None, H=None):
+        wa, wp = _hostptr(W, self.M, self.K)
+        ha, hp = _hostptr(H, self.K, self.N)
+        _chk(lib().nmf_solver_upload_pair(self._h, b, wp, hp))
+
+    def download_pair(self, b: int):
+        W = np.empty((self.M, self.K), dtype=np.float32, order="F")
+        H = np.empty((self.K, self.N), dtype=np.float32, order="F")
+        _chk(lib().nmf_solver_download_pair(self._h, b, W.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
+        return W, H
+
+    def check_pair(self, b: int):
+        kl, rl1 = C.c_double(), C.c_double()
+        _chk(lib().nmf_solver_check_pair(self._h, b, C.byref(kl), C.byref(rl1)))
+        return kl.value, rl1.value
+
+    def set_active(self, flags=None):
+        arr = None if flags is None else (C.c_int * self.batch)(*[int(bool(f)) for f in flags])
+        _chk(lib().nmf_solver_set_active(self._h, arr))
 
     def iterate(self, iters: int = 1):
         _chk(lib().nmf_solver_iterate(self._h, iters))

@@ -83,6 +83,7 @@ extern "C" void nmf_default_opts(nmf_opts *o) {
     o->nsplit_w = 0;
     o->fast_divide = 0;
     o->restart_lanes = 0;
+    o->split_kernel = 0;
 }
 
 static double now_s() {
@@ -97,6 +98,12 @@ struct nmf_solver {
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
     int fast_divide = 0;
+    // split path (nmf_split16.hip): four waves per 16 owned columns, normalisers summed in-stream, `batch` (W, H) pairs per launch
+    bool split = false;
+    int batch = 1;
+    int ns_h = 1, ns_w = 1;        // workgroup-level splits of the reduction dimension on the split path
+    float *vpart = nullptr;        // [batch][ns][Kp] per-split sums of the streamed factor
+    int *active_d = nullptr;       // [batch] device flags, nullptr = all pairs iterate
     bool x_shared = false;         // X belongs to another solver (update_div_restarts lanes)
     bool normW_fresh = false;      // normW = max(colsum(W), EPS) of the current W (left by the W-step's apply kernel): the H-step
                                    // may skip its column-sum launch.  Cleared by everything else that writes W.
@@ -150,15 +157,19 @@ static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
     return ns;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr);
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr, int batch = 1);
 
 extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nmf_opts *opts_in) {
-    if (!out || M <= 0 || N <= 0 || K <= 0) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
+    return nmf_solver_create_batched(out, M, N, K, 1, opts_in);
+}
+extern "C" int nmf_solver_create_batched(nmf_solver **out, int M, int N, int K, int batch, const nmf_opts *opts_in) {
+    if (!out || M <= 0 || N <= 0 || K <= 0 || batch < 1 || batch > 65535) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
     nmf_opts o;
     if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    if (batch > 1 && o.comm) { set_err("nmf_solver_create_batched: batched solvers do not shard"); return NMF_ERR_UNSUPPORTED; }
     if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
     nmf_solver *s = new nmf_solver();
-    const int st = solver_init(s, M, N, K, o);
+    const int st = solver_init(s, M, N, K, o, nullptr, batch);
     if (st != NMF_OK) {   // release whatever was allocated before the failure
         nmf_solver_destroy(s);
         return st;
@@ -167,18 +178,46 @@ extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nm
     return NMF_OK;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from) {
+// Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
+// launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
+// kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
+static int split_pad_k(int K) { return K <= 64 ? 64 : (K <= 128 ? 128 : 0); }
+static bool want_split(int M, int N, int K, const nmf_opts &o) {
+    const int kp = split_pad_k(K);
+    if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
+    if (((size_t)M + 127) * kp >= ((size_t)1 << 30) || ((size_t)N + 127) * kp >= ((size_t)1 << 30)) return false;
+    if (o.split_kernel > 0) return true;
+    return (size_t)M * (size_t)N <= ((size_t)1 << 26);
+}
+// workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128: one
+// workgroup per CU is the target; a function of the shape alone, so that a batched run equals its sequential twin bit for bit
+static int pick_split(int q_extent, int p_extent) {
+    const int tasks = q_extent / 16, nsc = p_extent / 128;
+    if (tasks >= 192 || nsc <= 1) return 1;
+    int S = (256 + tasks - 1) / tasks;
+    if (S > nsc) S = nsc;
+    const int scps = (nsc + S - 1) / S;
+    return (nsc + scps - 1) / scps;
+}
+
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch) {
     const double t0 = now_s();
     s->M = M; s->N = N; s->K = K;
-    s->Mp = pad32(M); s->Np = pad32(N);
     int path = o.path;
+    s->batch = batch;
+    s->split = want_split(M, N, K, o);
+    // the split kernel streams whole superchunks of 128: zero padding is invariant under the updates and adds nothing to any sum
+    s->Mp = s->split ? ((M + 127) & ~127) : pad32(M);
+    s->Np = s->split ? ((N + 127) & ~127) : pad32(N);
+    if (batch > 1 && !s->split) { set_err("batched solvers need the split kernel (K <= 128)"); return NMF_ERR_UNSUPPORTED; }
+    if (s->split) path = NMF_PATH_FUSED;
     // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
     const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << 31);
     if (path == NMF_PATH_AUTO) path = (fused_pad_k(K) && !k16_too_tall) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
         if (!fused_pad_k(K)) { set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
-        s->Kp = fused_pad_k(K);         // 32/64/128/256 (32x32x2 kernel) or 320/384/448/512 (16x16x4 kernel)
+        s->Kp = s->split ? split_pad_k(K) : fused_pad_k(K);   // 32/64/128/256 or 320/384/448/512; split kernel: 64/128
     } else {
         s->Kp = pad32(K);
     }
@@ -190,19 +229,32 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     else { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
     const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
-    NMFCHK(dev_alloc(&s->W, mk));
-    NMFCHK(dev_alloc(&s->H, kn));
+    NMFCHK(dev_alloc(&s->W, mk * batch));
+    NMFCHK(dev_alloc(&s->H, kn * batch));
     if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
     else NMFCHK(dev_alloc(&s->X, mn));
-    HIPCHK(hipMemsetAsync(s->W, 0, mk * sizeof(float), s->stream));
-    HIPCHK(hipMemsetAsync(s->H, 0, kn * sizeof(float), s->stream));
+    HIPCHK(hipMemsetAsync(s->W, 0, mk * batch * sizeof(float), s->stream));
+    HIPCHK(hipMemsetAsync(s->H, 0, kn * batch * sizeof(float), s->stream));
     if (!x_from) HIPCHK(hipMemsetAsync(s->X, 0, mn * sizeof(float), s->stream));
     NMFCHK(dev_alloc(&s->normW, (size_t)s->Kp));
     NMFCHK(dev_alloc(&s->normH, (size_t)s->Kp));
     NMFCHK(dev_alloc(&s->rowpart, (size_t)row_sum_blocks(s->Np) * s->Kp));
     NMFCHK(dev_alloc(&s->psum_owned, mk + (size_t)s->Kp));
     s->psum = s->psum_owned;
-    if (path == NMF_PATH_FUSED) {
+    if (s->split) {
+        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split(s->Np, s->Mp);
+        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split(s->Mp, s->Np);
+        const int nsc_h = s->Mp / 128, nsc_w = s->Np / 128;
+        if (s->ns_h > nsc_h) s->ns_h = nsc_h;
+        if (s->ns_w > nsc_w) s->ns_w = nsc_w;
+        s->nsplit_h = s->ns_h; s->nsplit_w = s->ns_w;
+        size_t pc = (size_t)s->ns_w * mk;                  // the W-step may always need slabs (sharded runs)
+        if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
+        NMFCHK(dev_alloc(&s->partials, pc * batch));
+        const int nsm = s->ns_h > s->ns_w ? s->ns_h : s->ns_w;
+        NMFCHK(dev_alloc(&s->vpart, (size_t)nsm * s->Kp * batch));
+        s->chk_groups = check_num_groups(s->Np, s->Kp);
+    } else if (path == NMF_PATH_FUSED) {
         const int qg = fused_cols_per_group(s->Kp);
         s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg);
         s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg);
@@ -243,12 +295,13 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
     if (s->graph8) (void)hipGraphDestroy(s->graph8);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    float *bufs[] = {s->W, s->H, s->x_shared ? nullptr : s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
+    float *bufs[] = {s->W, s->H, s->x_shared ? nullptr : s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->vpart, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
     for (float *b : bufs) if (b) (void)hipFree(b);
     if (s->chk_part) (void)hipFree(s->chk_part);
     if (s->chk_out) (void)hipFree(s->chk_out);
     if (s->chk_host) (void)hipHostFree(s->chk_host);
     if (s->range_flag) (void)hipFree(s->range_flag);
+    if (s->active_d) (void)hipFree(s->active_d);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -315,6 +368,51 @@ extern "C" int nmf_solver_download(nmf_solver *s, float *W, float *H) {
     return NMF_OK;
 }
 
+extern "C" int nmf_solver_batch(const nmf_solver *s) { return s ? s->batch : 0; }
+extern "C" int nmf_solver_uses_split_kernel(const nmf_solver *s) { return (s && s->split) ? 1 : 0; }
+extern "C" int nmf_solver_upload_pair(nmf_solver *s, int b, const float *W, const float *H) {
+    if (!s || b < 0 || b >= s->batch) return NMF_ERR_ARG;
+    if (b == 0) s->normW_fresh = false;
+    NMFCHK(upload_one(s, s->W + (size_t)b * s->Mp * s->Kp, s->Mp, s->Kp, W, s->M, s->K, true));
+    NMFCHK(upload_one(s, s->H + (size_t)b * s->Kp * s->Np, s->Kp, s->Np, H, s->K, s->N, true));
+    return NMF_OK;
+}
+extern "C" int nmf_solver_download_pair(nmf_solver *s, int b, float *W, float *H) {
+    if (!s || b < 0 || b >= s->batch) return NMF_ERR_ARG;
+    if (W) {
+        HIPCHK(launch_unpad_copy(s->staging, s->M, s->K, s->W + (size_t)b * s->Mp * s->Kp, s->Mp, s->stream));
+        HIPCHK(hipMemcpyAsync(W, s->staging, (size_t)s->M * s->K * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    if (H) {
+        HIPCHK(launch_unpad_copy(s->staging, s->K, s->N, s->H + (size_t)b * s->Kp * s->Np, s->Kp, s->stream));
+        HIPCHK(hipMemcpyAsync(H, s->staging, (size_t)s->K * s->N * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return NMF_OK;
+}
+// flags == nullptr re-activates every pair
+extern "C" int nmf_solver_set_active(nmf_solver *s, const int *flags) {
+    if (!s) return NMF_ERR_ARG;
+    if (!flags && !s->active_d) return NMF_OK;
+    if (!s->active_d) {   // the graphs captured so far hold a null flag pointer
+        if (s->graph_ready || s->graph8_ready) {
+            if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+            if (s->graph) (void)hipGraphDestroy(s->graph);
+            if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
+            if (s->graph8) (void)hipGraphDestroy(s->graph8);
+            s->graph = s->graph8 = nullptr; s->graph_exec = s->graph8_exec = nullptr;
+            s->graph_ready = s->graph8_ready = false;
+        }
+        HIPCHK(hipMalloc((void **)&s->active_d, sizeof(int) * (size_t)s->batch));
+    }
+    std::vector<int> f((size_t)s->batch, 1);
+    if (flags) for (int b = 0; b < s->batch; ++b) f[(size_t)b] = flags[b] ? 1 : 0;
+    HIPCHK(hipMemcpyAsync(s->active_d, f.data(), sizeof(int) * (size_t)s->batch, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NMF_OK;
+}
+
 // --------------------------------------------------------------------- piece timing
 struct PieceScope {
     nmf_solver *s; int idx = -1;
@@ -350,9 +448,43 @@ static FusedArgs fused_args(nmf_solver *s) {
     return a;
 }
 
+static SplitArgs split_args(nmf_solver *s) {
+    SplitArgs a;
+    a.W = s->W; a.H = s->H; a.X = s->X;
+    a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
+    a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np;
+    a.active = s->active_d;
+    a.fast_divide = s->fast_divide > 0;
+    a.x_in_range = s->fast_divide < 0 ? 0 : s->x_in_range;
+    return a;
+}
+// the split path's half-steps: one launch where the owned dimension alone fills the chip, else slabs + split_apply
+static int enqueue_split_h(nmf_solver *s) {
+    SplitArgs a = split_args(s);
+    a.nsplit = s->ns_h; a.U_out = s->H;
+    { PieceScope p(s, NMF_T_H_STEP); HIPCHK(launch_split_step(a, false, s->stream)); }
+    if (s->ns_h > 1) {
+        PieceScope p(s, NMF_T_APPLY);
+        HIPCHK(launch_split_apply(s->H, s->partials, s->vpart, s->ns_h, s->Mp, s->Np, s->Kp, false, s->batch, a.strideH, s->active_d, s->stream));
+    }
+    return NMF_OK;
+}
+static int enqueue_split_w(nmf_solver *s) {
+    SplitArgs a = split_args(s);
+    a.nsplit = s->ns_w; a.U_out = s->W;
+    { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_split_step(a, true, s->stream)); }
+    if (s->ns_w > 1) {
+        PieceScope p(s, NMF_T_APPLY);
+        HIPCHK(launch_split_apply(s->W, s->partials, s->vpart, s->ns_w, s->Mp, s->Np, s->Kp, true, s->batch, a.strideW, s->active_d, s->stream));
+    }
+    return NMF_OK;
+}
+
 // cuda/nmf.cu:118-146
 static int enqueue_update_h(nmf_solver *s) {
     hipStream_t st = s->stream;
+    if (s->split) return enqueue_split_h(s);
     if (s->path == NMF_PATH_FUSED) {
         if (!s->normW_fresh) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }
         FusedArgs a = fused_args(s);
@@ -394,6 +526,14 @@ static int enqueue_update_h(nmf_solver *s) {
 static int enqueue_w_partial(nmf_solver *s) {
     hipStream_t st = s->stream;
     const size_t mk = (size_t)s->Mp * s->Kp, mn = (size_t)s->Mp * s->Np;
+    if (s->split) {   // raw [Z*H' ; rowsum(H)]: one forced-partial split straight into psum, or slabs + their fixed-order sum
+        SplitArgs a = split_args(s);
+        a.nsplit = s->ns_w; a.force_partial = 1;
+        if (s->ns_w == 1) { a.partials = s->psum; a.vpart = s->psum + mk; }
+        { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_split_step(a, true, st)); }
+        if (s->ns_w > 1) { PieceScope p(s, NMF_T_APPLY); HIPCHK(launch_sum_partials(s->psum, s->partials, s->ns_w, mk, st, s->vpart, s->Kp)); }
+        return NMF_OK;
+    }
     // rowsum(H) (the tail of the all-reduce operand) comes out of the W-step kernel where it can (FusedArgs::vsum_part)
     const bool vs = s->path == NMF_PATH_FUSED && fused_streams_vsum(s->Mp, s->Kp) && (s->nsplit_w == 1 || s->vsum_part);
     if (!vs) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->psum + mk, /*clamp=*/false, st)); }
@@ -440,6 +580,7 @@ static int enqueue_update_w(nmf_solver *s) {
         { PieceScope p(s, NMF_T_ALLREDUCE); NMFCHK(nmf_comm_allreduce_f32(s->comm, s->psum, mk + (size_t)s->Kp, st)); }
         return enqueue_w_apply(s);
     }
+    if (s->split) return enqueue_split_w(s);
     if (s->path == NMF_PATH_FUSED) {
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_w;
@@ -501,6 +642,7 @@ extern "C" int nmf_solver_update_w(nmf_solver *s) {
 }
 extern "C" int nmf_solver_w_partial(nmf_solver *s) {
     if (!s) return NMF_ERR_ARG;
+    if (s->batch > 1) { set_err("w_partial: batched solvers do not shard"); return NMF_ERR_UNSUPPORTED; }
     s->external_reduce = true;
     return enqueue_w_partial(s);
 }
@@ -556,6 +698,7 @@ static int ensure_graph8(nmf_solver *s) {
 // does the W half-step as this solver runs it end in launch_apply_w_colsum (which leaves normW for the next H-step)?
 static bool w_step_refreshes_normW(const nmf_solver *s) {
     if (s->Mp > kMaxRowsApplyColsum) return false;
+    if (s->split) return false;   // the split kernel sums its normaliser from the factor it streams
     return s->comm ? true : (s->path == NMF_PATH_FUSED && s->nsplit_w > 1);
 }
 
@@ -607,13 +750,13 @@ extern "C" int nmf_solver_iterate_timed(nmf_solver *s, int iters, double t[10]) 
 }
 
 // KL / rel-L1 of the current state (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640)
-extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) {
-    if (!s || !sums) return NMF_ERR_ARG;
+static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
+    if (!s || !sums || b < 0 || b >= s->batch) return NMF_ERR_ARG;
     hipStream_t st = s->stream;
     {
         PieceScope p(s, NMF_T_CHECK);
         if (s->path == NMF_PATH_FUSED) {
-            HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+            HIPCHK(launch_check(s->W + (size_t)b * s->Mp * s->Kp, s->H + (size_t)b * s->Kp * s->Np, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
         } else {
             const size_t mn = (size_t)s->Mp * s->Np;
             HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
@@ -626,6 +769,14 @@ extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) {
     HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     sums[0] = s->chk_host[0]; sums[1] = s->chk_host[1]; sums[2] = s->chk_host[2];
+    return NMF_OK;
+}
+extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) { return check_sums_pair(s, 0, sums); }
+extern "C" int nmf_solver_check_pair(nmf_solver *s, int b, double *kl, double *rel_l1) {
+    double v[3];
+    NMFCHK(check_sums_pair(s, b, v));
+    if (kl) *kl = v[0];
+    if (rel_l1) *rel_l1 = (v[2] > 0.0) ? v[1] / v[2] : 0.0;
     return NMF_OK;
 }
 extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
@@ -698,11 +849,13 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
         switch (which) {
             case NMF_T_H_STEP:
                 if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
+                if (s->split) { SplitArgs sa = split_args(s); sa.nsplit = s->ns_h; sa.U_out = s->H; HIPCHK(launch_split_step(sa, false, st)); break; }
                 fa.nsplit = s->nsplit_h; fa.partial = s->nsplit_h > 1; fa.U_out = s->H; fa.norm = s->normW; fa.partials = s->partials;
                 HIPCHK(launch_fused_step(fa, false, st));
                 break;
             case NMF_T_W_STEP:
                 if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
+                if (s->split) { SplitArgs sa = split_args(s); sa.nsplit = s->ns_w; sa.U_out = s->W; HIPCHK(launch_split_step(sa, true, st)); break; }
                 fa.nsplit = s->nsplit_w; fa.partial = s->nsplit_w > 1; fa.U_out = s->W; fa.norm = s->normH; fa.partials = s->partials;
                 HIPCHK(launch_fused_step(fa, true, st));
                 break;

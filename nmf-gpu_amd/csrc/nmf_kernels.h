@@ -51,6 +51,32 @@ hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream);   // diag
 hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipStream_t stream);   // diagnostic
 hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream);     // diagnostic (slice -1: rcp invariance)
 hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream);   // timing probes (v1 kernel + ablation mask)
+// ---------------------------------------------------------------- split half-steps (nmf_split16.hip)
+// The half-step for problems whose owned dimension is too short to fill the chip with one workgroup per 64 columns: the
+// four waves of a workgroup own the SAME 16 columns and split the reduction dimension (summed through LDS in fixed
+// order), the normaliser is summed from the streamed factor in the same pass, and blockIdx.y indexes `batch` independent
+// (W, H) pairs against one X.  nsplit == 1: U_out is updated in place by the launch itself.  nsplit > 1: raw slabs
+// [batch][nsplit][U] in `partials` plus the per-split sums of the streamed factor [batch][nsplit][Kp] in `vpart`,
+// finished by launch_split_apply.
+struct SplitArgs {
+    const float *W; const float *H; const float *X;   // W: [batch] Mp x Kp, H: [batch] Kp x Np, X: Mp x Np (shared)
+    float *U_out;             // nsplit == 1: base of the owned factor (H for the H-step, W for the W-step)
+    float *partials;          // nsplit  > 1
+    float *vpart;             // nsplit  > 1
+    int Mp, Np, Kp;
+    int nsplit;
+    int force_partial;        // 1: raw slab + sums even with nsplit == 1 (sharded runs: the all-reduce operand)
+    int batch;
+    size_t strideW, strideH;  // floats between consecutive pairs
+    const int *active;        // optional [batch] flags: 0 = leave this pair untouched (it has converged)
+    int fast_divide, x_in_range;
+};
+bool       split_step_supports(int Kp);
+size_t     split_step_lds_bytes(int Kp);
+hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream);
+hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, bool wstep,
+                              int batch, size_t ustride, const int *active, hipStream_t stream);
+
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
 // norm == nullptr (W-step only): the normaliser is max(sum_s vsum_part[s][k], EPS) instead
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
