@@ -102,6 +102,7 @@ struct nmf_solver {
     bool split = false;
     int batch = 1;
     int ns_h = 1, ns_w = 1;        // workgroup-level splits of the reduction dimension on the split path
+    int nw_h = 4, nw_w = 4;        // waves per workgroup of the two half-steps (8 where K = 64 and the reduction length allows)
     float *vpart = nullptr;        // [batch][ns][Kp] per-split sums of the streamed factor
     int *active_d = nullptr;       // [batch] device flags, nullptr = all pairs iterate
     bool x_shared = false;         // X belongs to another solver (update_div_restarts lanes)
@@ -191,10 +192,11 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128: one
 // workgroup per CU is the target; a function of the shape alone, so that a batched run equals its sequential twin bit for bit
-static int pick_split(int q_extent, int p_extent) {
-    const int tasks = q_extent / 16, nsc = p_extent / 128;
+static int pick_split(int q_valid, int p_extent, int sc_rows) {
+    const int tasks = q_valid / 16, nsc = p_extent / sc_rows;
     if (tasks >= 192 || nsc <= 1) return 1;
-    int S = (256 + tasks - 1) / tasks;
+    int S = 256 / tasks;             // never more workgroups than CUs: a second round costs more than the shorter loop saves
+    if (S < 1) S = 1;
     if (S > nsc) S = nsc;
     const int scps = (nsc + S - 1) / S;
     return (nsc + scps - 1) / scps;
@@ -242,15 +244,25 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     NMFCHK(dev_alloc(&s->psum_owned, mk + (size_t)s->Kp));
     s->psum = s->psum_owned;
     if (s->split) {
-        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split(s->Np, s->Mp);
-        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split(s->Mp, s->Np);
-        const int nsc_h = s->Mp / 128, nsc_w = s->Np / 128;
+        // eight waves per workgroup (two per SIMD from a single workgroup per CU) where K = 64 leaves the LDS for eight sub-images
+        // (measured: 3 % on cfg2 alone, but 17 % slower than two independent four-wave workgroups per CU once a batch fills
+        //  the chip -- the eight waves share one barrier and run in phase -- so it stays an experiment: NMF_SPLIT_NW=8)
+        const char *nwe = getenv("NMF_SPLIT_NW");
+        const bool nw8 = s->Kp == 64 && nwe && nwe[0] == '8';
+        s->nw_h = (nw8 && s->Mp % 256 == 0) ? 8 : 4;
+        s->nw_w = (nw8 && s->Np % 256 == 0) ? 8 : 4;
+        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h);
+        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w);
+        const int nsc_h = s->Mp / (32 * s->nw_h), nsc_w = s->Np / (32 * s->nw_w);
         if (s->ns_h > nsc_h) s->ns_h = nsc_h;
         if (s->ns_w > nsc_w) s->ns_w = nsc_w;
         s->nsplit_h = s->ns_h; s->nsplit_w = s->ns_w;
         size_t pc = (size_t)s->ns_w * mk;                  // the W-step may always need slabs (sharded runs)
         if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
         NMFCHK(dev_alloc(&s->partials, pc * batch));
+        // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
+        HIPCHK(hipMemsetAsync(s->partials, 0, pc * batch * sizeof(float), s->stream));
+        HIPCHK(hipMemsetAsync(s->psum_owned, 0, (mk + (size_t)s->Kp) * sizeof(float), s->stream));
         const int nsm = s->ns_h > s->ns_w ? s->ns_h : s->ns_w;
         NMFCHK(dev_alloc(&s->vpart, (size_t)nsm * s->Kp * batch));
         s->chk_groups = check_num_groups(s->Np, s->Kp);
@@ -453,6 +465,8 @@ static SplitArgs split_args(nmf_solver *s) {
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
     a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
+    a.nw_h = s->nw_h; a.nw_w = s->nw_w;
+    a.Mv = (s->M + 31) & ~31; a.Nv = (s->N + 31) & ~31;
     a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np;
     a.active = s->active_d;
     a.fast_divide = s->fast_divide > 0;
@@ -466,7 +480,7 @@ static int enqueue_split_h(nmf_solver *s) {
     { PieceScope p(s, NMF_T_H_STEP); HIPCHK(launch_split_step(a, false, s->stream)); }
     if (s->ns_h > 1) {
         PieceScope p(s, NMF_T_APPLY);
-        HIPCHK(launch_split_apply(s->H, s->partials, s->vpart, s->ns_h, s->Mp, s->Np, s->Kp, false, s->batch, a.strideH, s->active_d, s->stream));
+        HIPCHK(launch_split_apply(s->H, s->partials, s->vpart, s->ns_h, s->Mp, s->Np, s->Kp, a.Nv, false, s->batch, a.strideH, s->active_d, s->stream));
     }
     return NMF_OK;
 }
@@ -476,7 +490,7 @@ static int enqueue_split_w(nmf_solver *s) {
     { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_split_step(a, true, s->stream)); }
     if (s->ns_w > 1) {
         PieceScope p(s, NMF_T_APPLY);
-        HIPCHK(launch_split_apply(s->W, s->partials, s->vpart, s->ns_w, s->Mp, s->Np, s->Kp, true, s->batch, a.strideW, s->active_d, s->stream));
+        HIPCHK(launch_split_apply(s->W, s->partials, s->vpart, s->ns_w, s->Mp, s->Np, s->Kp, a.Mv, true, s->batch, a.strideW, s->active_d, s->stream));
     }
     return NMF_OK;
 }
@@ -658,6 +672,10 @@ extern "C" int nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size
     if (!s || !dev_ptr) return NMF_ERR_ARG;
     if (count < (size_t)s->Mp * s->Kp + (size_t)s->Kp) { set_err("partial buffer too small"); return NMF_ERR_ARG; }
     if (s->graph_ready) { set_err("partial buffer must be set before the first iterate()"); return NMF_ERR_UNSUPPORTED; }
+    if (s->split) {   // entries of zero-padding rows are never written by the split kernel
+        HIPCHK(hipMemsetAsync(dev_ptr, 0, count * sizeof(float), s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     s->psum = dev_ptr;
     return NMF_OK;
 }

@@ -64,7 +64,9 @@ struct SplitArgs {
     float *partials;          // nsplit  > 1
     float *vpart;             // nsplit  > 1
     int Mp, Np, Kp;
+    int Mv, Nv;               // M, N rounded up to 32: column groups beyond them hold only zero padding and get no workgroup
     int nsplit;
+    int nw_h, nw_w;           // waves per workgroup (4 or 8) of the H- and the W-step: reduction length % (32 nw) == 0; 8 needs Kp == 64
     int force_partial;        // 1: raw slab + sums even with nsplit == 1 (sharded runs: the all-reduce operand)
     int batch;
     size_t strideW, strideH;  // floats between consecutive pairs
@@ -72,9 +74,10 @@ struct SplitArgs {
     int fast_divide, x_in_range;
 };
 bool       split_step_supports(int Kp);
-size_t     split_step_lds_bytes(int Kp);
+size_t     split_step_lds_bytes(int Kp, int nw);
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream);
-hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, bool wstep,
+// q_valid: rows of W (W-step) / columns of H (H-step) that got a workgroup (SplitArgs::Mv / Nv); the rest is zero padding
+hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, int q_valid, bool wstep,
                               int batch, size_t ustride, const int *active, hipStream_t stream);
 
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)

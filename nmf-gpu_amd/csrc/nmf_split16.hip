@@ -27,12 +27,16 @@ typedef const __attribute__((address_space(1))) char *global_bytes;
 #define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int kXs16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
 
-template <int NB, bool WSTEP, bool PARTIAL, int DIV, int OCC>
-__global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
+// NW = waves per workgroup = 32-row sub-images per superchunk (4, or 8 at K = 64: one workgroup then puts two waves on
+// every SIMD of its CU, and each fills the other's quotient / wait / barrier time with MFMAs -- what a second workgroup
+// per CU does for the 64-column kernel, for shapes with no more than one workgroup per CU to hand out).
+template <int NB, int NW, bool WSTEP, bool PARTIAL, int DIV, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 64 * NB;
     constexpr int VBUF = K * kLdv;   // one 32-wide sub-image
-    constexpr int IMG = 4 * VBUF;    // one superchunk
+    constexpr int IMG = NW * VBUF;   // one superchunk
+    constexpr int SH = NW / 4;       // sub-images staged per pass of the workgroup's 8 NW piece slots (32 slots per sub-image)
     constexpr int N1 = 16 * NB;      // product-1 steps per 16-row tile
     constexpr int NT = 4 * NB;       // 16 x 16 accumulator tiles
     constexpr int NST = 2 * NB;      // staged 16-B pieces per thread per 32-row chunk
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y;
     if (a.active != nullptr && a.active[b] == 0) return;
-    const int P = WSTEP ? a.Np : a.Mp;   // a multiple of 128: every superchunk is whole
+    const int P = WSTEP ? a.Np : a.Mp;   // a multiple of 32 NW: every superchunk is whole
     const int nsplit = a.nsplit;
     const bool x_in_range = a.x_in_range != 0;
     int split, qblk;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
     const float *__restrict__ V = WSTEP ? Hb : Wb;
     const float *__restrict__ U = WSTEP ? Wb : Hb;
     const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
-    const int nsc = P / 128;
+    const int nsc = P / (32 * NW);
     const int scps = (nsc + nsplit - 1) / nsplit;
     const int sc_begin = split * scps;
     const int sc_end = (sc_begin + scps < nsc) ? (sc_begin + scps) : nsc;
@@ -86,15 +90,19 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // sums of the streamed factor over the pieces this thread stages.  H-step: piece = 4 consecutive rows p of column
-    // k = (tid >> 3) + 32 qq of W; W-step: piece = rows k = 4 (8 qq + (tid & 7)) .. + 3 of column p of H.
+    // k = g + 32 qq of W; W-step: piece = rows k = 4 (8 qq + (tid & 7)) .. + 3 of column p = g of H, where g = (tid >> 3) & 31
+    // and pass sp of the staging puts this thread on sub-image SH sp + (tid >> 8).
+    const int g = (tid >> 3) & 31, sub_hi = tid >> 8;
+    // PARTIAL: the sums go to vpart, which only the workgroups of the first column group write
+    const bool vs_on = !PARTIAL || qblk == 0;
     f32x4 vs[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) vs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (sc_begin < sc_end) {
-        const unsigned voff0 = 4u * ((unsigned)(4 * (tid & 7)) + (unsigned)(tid >> 3) * (unsigned)ldv);
         const unsigned vstep = 4u * (WSTEP ? 32u : 32u * (unsigned)ldv);              // bytes between the pieces of one chunk
         const size_t vchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldv : (size_t)32);    // bytes between chunks
+        const unsigned voff0 = 4u * ((unsigned)(4 * (tid & 7)) + (unsigned)g * (unsigned)ldv) + (unsigned)sub_hi * (unsigned)vchunk;
         // X tile (32 p x 16 q): H-step 16 columns of 128 B (8 lanes per column), W-step 32 rows of 64 B (4 lanes per row)
         const unsigned xoff0 = WSTEP ? 4u * ((unsigned)(4 * (lane & 3)) + (unsigned)(lane >> 2) * (unsigned)ldx)
                                      : 4u * ((unsigned)(4 * (lane & 7)) + (unsigned)(lane >> 3) * (unsigned)ldx);
@@ -119,16 +127,16 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
         auto set_v = [&](int sc) {
             vo = voff0;
             asm volatile("" : "+v"(vo));
-            vcur = reinterpret_cast<const char *>(V) + (size_t)(4 * sc) * vchunk;
+            vcur = reinterpret_cast<const char *>(V) + (size_t)(NW * sc) * vchunk;
         };
         auto set_x = [&](int sc) {
             xo = xoff0;
             asm volatile("" : "+v"(xo));
-            xcur = xbase + (size_t)(4 * sc + wave) * xchunk;
+            xcur = xbase + (size_t)(NW * sc + wave) * xchunk;
         };
-        auto stage_load_one = [&](int w) {   // piece w = (sub, qq)
-            const int sub = w / NST, qq = w % NST;
-            global_bytes base = (global_bytes)(vcur + (size_t)sub * vchunk + (size_t)qq * (size_t)vstep);
+        auto stage_load_one = [&](int w) {   // piece w = (pass sp, qq)
+            const int sp = w / NST, qq = w % NST;
+            global_bytes base = (global_bytes)(vcur + (size_t)(SH * sp) * vchunk + (size_t)qq * (size_t)vstep);
             asm volatile("" : "+s"(base));
             st[w] = *(const __attribute__((address_space(1))) f32x4 *)(base + vo);
         };
@@ -137,12 +145,13 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
             asm volatile("" : "+s"(base));
             xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
         };
-        auto stage_store_one = [&](float *__restrict__ img, int w4) {   // one ds_write_b32 of piece w4 / 4
-            const int w = w4 / 4, cc = w4 % 4, sub = w / NST, qq = w % NST;
-            float *__restrict__ vl = img + sub * VBUF;
-            if (!WSTEP) { const int k = (tid >> 3) + 32 * qq, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[w][cc]; }
-            else        { const int k4 = qq * 8 + (tid & 7), i = tid >> 3; vl[(4 * k4 + cc) * kLdv + i] = st[w][cc]; }
-            if (cc == 3) {   // the piece is complete: add it to this thread's share of the streamed factor's sums
+        const int img_off = sub_hi * VBUF + (WSTEP ? 4 * (tid & 7) * kLdv + g : g * kLdv + 4 * (tid & 7));
+        auto stage_store_one = [&](float *__restrict__ img, int w4, auto vs_tag) {   // one ds_write_b32 of piece w4 / 4
+            const int w = w4 / 4, cc = w4 % 4, sp = w / NST, qq = w % NST;
+            float *__restrict__ vl = img + img_off + SH * sp * VBUF;
+            if (!WSTEP) vl[32 * qq * kLdv + cc] = st[w][cc];
+            else        vl[(32 * qq + cc) * kLdv] = st[w][cc];
+            if (decltype(vs_tag)::value && cc == 3) {   // the piece is complete: add it to this thread's share of the streamed factor's sums
                 if (!WSTEP) vs[qq][0] += (st[w][0] + st[w][1]) + (st[w][2] + st[w][3]);
                 else        vs[qq] += st[w];
             }
@@ -180,13 +189,13 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) x_load_one(i);
 #pragma unroll
-        for (int w4 = 0; w4 < 4 * NPC; ++w4) stage_store_one(smem, w4);
+        for (int w4 = 0; w4 < 4 * NPC; ++w4) stage_store_one(smem, w4, std::true_type{});
         x_fetch();
         x_park();
         __syncthreads();
 
-        // one superchunk; LAST: nothing left to stage (the peeled final iteration)
-        auto body = [&](int sc, auto last_tag) {
+        // one superchunk; LAST: nothing left to stage (the peeled final iteration); VS: this workgroup's sums are needed
+        auto body = [&](int sc, auto last_tag, auto vs_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             const int rel = sc - sc_begin, par = rel & 1;
             const float *__restrict__ vb = smem + par * IMG + wave * VBUF;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
                         a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
                     }
                     if (!LAST && e < 4 * NPC) {   // 4 * NPC == E2: exactly one per MFMA
-                        stage_store_one(vn, e);
+                        stage_store_one(vn, e, vs_tag);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -254,21 +263,23 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
             if (!LAST) x_park();    // the tile of superchunk sc + 2
             __syncthreads();
         };
-        for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{});
-        body(sc_last, std::true_type{});
+        if (vs_on) for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::true_type{});
+        else       for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::false_type{});
+        body(sc_last, std::true_type{}, std::false_type{});
     }
 
     // ---- the four waves' accumulators -> one (fixed order), the streamed factor's sums -> K normalisers
     // red[w][t][lane] (f32x4) at smem, vsl[slot][k] behind it; the superchunk images are dead (barrier above)
     f32x4 *red = reinterpret_cast<f32x4 *>(smem);
-    float *vsl = smem + 4 * NT * 64 * 4;
-    float *nrm_l = vsl + 32 * K;
+    float *vsl = smem + NW * NT * 64 * 4;
+    constexpr int NSLOT = WSTEP ? 8 * NW : 8 * SH;
+    float *nrm_l = vsl + NSLOT * K;
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
-    if (!WSTEP) {   // slot = tid & 7 (8 threads share a column k of W)
+    if (!WSTEP) {   // slot = (tid & 7, sub_hi): 8 SH threads share a column k of W
 #pragma unroll
-        for (int qq = 0; qq < NST; ++qq) vsl[(tid & 7) * K + (tid >> 3) + 32 * qq] = vs[qq][0];
-    } else {        // slot = tid >> 3 (32 threads share four rows k of H)
+        for (int qq = 0; qq < NST; ++qq) vsl[((tid & 7) + 8 * sub_hi) * K + g + 32 * qq] = vs[qq][0];
+    } else {        // slot = tid >> 3: 8 NW threads share four rows k of H
 #pragma unroll
         for (int qq = 0; qq < NST; ++qq)
 #pragma unroll
@@ -276,7 +287,6 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
     }
     __syncthreads();
     if (tid < K) {
-        constexpr int NSLOT = WSTEP ? 32 : 8;
         float n = vsl[tid];
 #pragma unroll
         for (int sl = 1; sl < NSLOT; ++sl) n += vsl[sl * K + tid];
@@ -284,13 +294,18 @@ __global__ __launch_bounds__(256, OCC) void split_step_kernel_k16(SplitArgs a) {
         else nrm_l[tid] = clamp_eps(n);
     }
     if (!PARTIAL) __syncthreads();
-    // wave w finishes tiles t = w, w + 4, ...: lane holds Acc(k = 16 t + 4 kq + r, q0 + j)
+    // wave w finishes tiles t = w, w + NW, ...: lane holds Acc(k = 16 t + 4 kq + r, q0 + j)
     const size_t ustride = WSTEP ? a.strideW : a.strideH;
 #pragma unroll
-    for (int tt = 0; tt < NB; ++tt) {
-        const int t = wave + 4 * tt;
+    for (int tt = 0; tt < (NT + NW - 1) / NW; ++tt) {
+        const int t = wave + NW * tt;
+        if (t >= NT) break;
         const f32x4 r0 = red[(0 * NT + t) * 64 + lane], r1 = red[(1 * NT + t) * 64 + lane], r2 = red[(2 * NT + t) * 64 + lane], r3 = red[(3 * NT + t) * 64 + lane];
-        const f32x4 sum = (r0 + r1) + (r2 + r3);
+        f32x4 sum = (r0 + r1) + (r2 + r3);
+        if (NW == 8) {
+            const f32x4 r4 = red[(4 * NT + t) * 64 + lane], r5 = red[(5 * NT + t) * 64 + lane], r6 = red[(6 * NT + t) * 64 + lane], r7 = red[(7 * NT + t) * 64 + lane];
+            sum += (r4 + r5) + (r6 + r7);
+        }
         const int k = 16 * t + 4 * kq;
         if (PARTIAL) {
             const size_t slab = WSTEP ? (size_t)a.Mp * a.Kp : (size_t)a.Kp * a.Np;
@@ -335,13 +350,14 @@ __device__ __forceinline__ f32x4 slab_sum4(const float *__restrict__ p, size_t s
 }
 template <bool WSTEP>
 __global__ __launch_bounds__(256) void split_apply_kernel(float *__restrict__ U, const float *__restrict__ P, const float *__restrict__ vpart, int nsplit,
-                                                          size_t count, size_t ustride, int Mp, int Kp, const int *__restrict__ active) {
+                                                          size_t count, size_t todo, size_t ustride, int Mp, int Kp, int q_valid, const int *__restrict__ active) {
     const int b = blockIdx.y;
     if (active != nullptr && active[b] == 0) return;
     float *__restrict__ Ub = U + (size_t)b * ustride;
     const float *__restrict__ Pb = P + (size_t)b * nsplit * count;
     const float *__restrict__ vb = vpart + (size_t)b * nsplit * Kp;
-    for (size_t i = 4 * ((size_t)blockIdx.x * 256 + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * 256) {
+    for (size_t i = 4 * ((size_t)blockIdx.x * 256 + threadIdx.x); i < todo; i += 4 * (size_t)gridDim.x * 256) {
+        if (WSTEP && (int)(i % (size_t)Mp) >= q_valid) continue;   // zero padding: no workgroup wrote these slab entries
         const f32x4 s = slab_sum4(Pb + i, count, nsplit);
         f32x4 u = *reinterpret_cast<const f32x4 *>(Ub + i);
         if (WSTEP) {   // W (Mp x Kp): the four elements share column k (Mp % 4 == 0)
@@ -361,23 +377,24 @@ __global__ __launch_bounds__(256) void split_apply_kernel(float *__restrict__ U,
     }
 }
 
-hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, bool wstep,
+hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, int q_valid, bool wstep,
                               int batch, size_t ustride, const int *active, hipStream_t stream) {
-    const size_t count = wstep ? (size_t)Mp * Kp : (size_t)Kp * Np;
-    size_t g = (count / 4 + 255) / 256;
+    const size_t count = wstep ? (size_t)Mp * Kp : (size_t)Kp * Np;       // slab stride
+    const size_t todo = wstep ? count : (size_t)Kp * q_valid;             // H: the valid columns are a prefix
+    size_t g = (todo / 4 + 255) / 256;
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     const dim3 grid((unsigned)g, (unsigned)batch);
-    if (wstep) hipLaunchKernelGGL(split_apply_kernel<true>, grid, dim3(256), 0, stream, U, partials, vpart, nsplit, count, ustride, Mp, Kp, active);
-    else       hipLaunchKernelGGL(split_apply_kernel<false>, grid, dim3(256), 0, stream, U, partials, vpart, nsplit, count, ustride, Mp, Kp, active);
+    if (wstep) hipLaunchKernelGGL(split_apply_kernel<true>, grid, dim3(256), 0, stream, U, partials, vpart, nsplit, count, todo, ustride, Mp, Kp, q_valid, active);
+    else       hipLaunchKernelGGL(split_apply_kernel<false>, grid, dim3(256), 0, stream, U, partials, vpart, nsplit, count, todo, ustride, Mp, Kp, q_valid, active);
     return hipGetLastError();
 }
 
-template <int NB, int OCC>
+template <int NB, int NW, int OCC>
 static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t stream) {
-    const int Q = wstep ? a.Mp : a.Np;
-    const dim3 grid((unsigned)((Q / 16) * a.nsplit), (unsigned)a.batch), block(256);
-    const size_t lds = split_step_lds_bytes(a.Kp);
+    const int Q = wstep ? a.Mv : a.Nv;   // the column groups beyond hold zero padding only: it stays zero without being touched
+    const dim3 grid((unsigned)((Q / 16) * a.nsplit), (unsigned)a.batch), block(64 * NW);
+    const size_t lds = split_step_lds_bytes(a.Kp, NW);
     const bool partial = a.nsplit > 1 || a.force_partial;
     const bool fast = fused_fast_divide() || a.fast_divide;
 #define NMF_LAUNCH_S16(...)                                                                               \
@@ -387,31 +404,34 @@ static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t s
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
     if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, false, false, 1, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, false, true, 1, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, true, false, 1, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, true, true, 1, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, false, 1, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, true, 1, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, false, 1, OCC>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, true, 1, OCC>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, false, false, 0, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, false, true, 0, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, true, false, 0, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, true, true, 0, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, false, 0, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, true, 0, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, false, 0, OCC>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, true, 0, OCC>);
     }
 #undef NMF_LAUNCH_S16
     return hipGetLastError();
 }
 
-size_t split_step_lds_bytes(int Kp) { return ((size_t)2 * 4 * Kp * kLdv + 4 * kXs16Floats) * sizeof(float); }
+size_t split_step_lds_bytes(int Kp, int nw) { return ((size_t)2 * nw * Kp * kLdv + nw * kXs16Floats) * sizeof(float); }
 bool split_step_supports(int Kp) { return Kp == 64 || Kp == 128; }
 
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream) {
-    if ((a.Mp | a.Np) & 127) return hipErrorInvalidValue;   // whole superchunks: the solver pads to 128 on this path
+    const int nw = wstep ? a.nw_w : a.nw_h;
+    if ((nw != 4 && nw != 8) || (nw == 8 && a.Kp != 64)) return hipErrorInvalidValue;
+    if ((a.Mv & 31) || (a.Nv & 31) || a.Mv > a.Mp || a.Nv > a.Np || a.Mv <= 0 || a.Nv <= 0) return hipErrorInvalidValue;
+    if (((a.Mp | a.Np) & 127) || ((wstep ? a.Np : a.Mp) % (32 * nw))) return hipErrorInvalidValue;   // whole superchunks: the solver pads
     const bool partial = a.nsplit > 1 || a.force_partial;
     if (a.nsplit < 1 || a.batch < 1 || (partial && (!a.partials || !a.vpart)) || (!partial && !a.U_out)) return hipErrorInvalidValue;
     if ((size_t)a.Mp * (size_t)a.Kp >= ((size_t)1 << 30) || (size_t)a.Kp * (size_t)a.Np >= ((size_t)1 << 30)) return hipErrorInvalidValue;   // 32-bit lane offsets
     switch (a.Kp) {
-        case 64:  return launch_split_k16<1, 2>(a, wstep, stream);
-        case 128: return launch_split_k16<2, 1>(a, wstep, stream);
+        case 64:  return nw == 8 ? launch_split_k16<1, 8, 2>(a, wstep, stream) : launch_split_k16<1, 4, 2>(a, wstep, stream);
+        case 128: return launch_split_k16<2, 4, 1>(a, wstep, stream);
         default:  return hipErrorInvalidValue;
     }
 }
