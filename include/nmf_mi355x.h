@@ -103,9 +103,10 @@ typedef struct {
                              * -1: always the full sequence (for A/B tests of the above);
                              * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
                              *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
-    int   restart_lanes;    /* update_div_restarts only: how many initialisations iterate concurrently, each on its own stream
-                             * against the one resident X (small problems fill a fraction of the 256 CUs per launch);
-                             * 0 = automatic (two lanes unless one launch already fills the chip), 1 = one after the other */
+    int   restart_lanes;    /* update_div_restarts only.  0 = automatic: shapes the split kernel takes (K <= 128, see split_kernel)
+                             * run ALL restarts in every launch (the restart index is a grid dimension); other shapes iterate two
+                             * initialisations side by side on their own streams unless one launch already fills the chip.
+                             * n > 0: n stream lanes (1 = one restart after the other), never the batched grid */
     int   split_kernel;     /* which fused kernel family: 0 = automatic; 1 = the split kernel (four waves per 16 owned columns,
                              * normalisers summed in-stream, two to four launches per iteration: problems that do not fill
                              * the chip, K <= 128); -1 = never (the 64-column kernel of the large configurations) */
@@ -219,6 +220,8 @@ int  nmf_solver_upload_pair(nmf_solver *s, int b, const float *W, const float *H
 int  nmf_solver_download_pair(nmf_solver *s, int b, float *W, float *H);
 int  nmf_solver_check_pair(nmf_solver *s, int b, double *kl, double *rel_l1);
 int  nmf_solver_set_active(nmf_solver *s, const int *flags);
+/* KL and rel-L1 of every pair (arrays of `batch` doubles, either may be NULL) behind one synchronisation */
+int  nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1);
 /* 1 if this solver runs the split kernel (see nmf_opts.split_kernel) */
 int  nmf_solver_uses_split_kernel(const nmf_solver *s);
 int  nmf_solver_path(const nmf_solver *s);

@@ -109,6 +109,7 @@ _SIGS = [
     ("nmf_solver_download_pair", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("nmf_solver_check_pair", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("nmf_solver_set_active", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    ("nmf_solver_check_all", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("nmf_solver_uses_split_kernel", C.c_int, [C.c_void_p]),
     ("nmf_solver_path", C.c_int, [C.c_void_p]),
     ("nmf_solver_stream", C.c_void_p, [C.c_void_p]),
@@ -468,6 +469,11 @@ class Solver:
         kl, rl1 = C.c_double(), C.c_double()
         _chk(lib().nmf_solver_check_pair(self._h, b, C.byref(kl), C.byref(rl1)))
         return kl.value, rl1.value
+
+    def check_all(self):
+        kl, rl1 = (C.c_double * self.batch)(), (C.c_double * self.batch)()
+        _chk(lib().nmf_solver_check_all(self._h, kl, rl1))
+        return list(kl), list(rl1)
 
     def set_active(self, flags=None):
         arr = None if flags is None else (C.c_int * self.batch)(*[int(bool(f)) for f in flags])

@@ -287,8 +287,14 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         s->chk_groups = reduce_num_groups(mn);
     }
     HIPCHK(hipMalloc((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups));
-    HIPCHK(hipMalloc((void **)&s->chk_out, sizeof(double) * 3));
-    HIPCHK(hipHostMalloc((void **)&s->chk_host, sizeof(double) * 3, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch));
+    HIPCHK(hipHostMalloc((void **)&s->chk_host, sizeof(double) * 3 * (size_t)batch, hipHostMallocDefault));
+    if (batch > 1) {   // the flag array exists from the start, so that captured graphs never hold a stale null pointer
+        HIPCHK(hipMalloc((void **)&s->active_d, sizeof(int) * (size_t)batch));
+        std::vector<int> ones((size_t)batch, 1);
+        HIPCHK(hipMemcpyAsync(s->active_d, ones.data(), sizeof(int) * (size_t)batch, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     HIPCHK(hipMalloc((void **)&s->range_flag, sizeof(unsigned)));
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
@@ -790,6 +796,25 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
     return NMF_OK;
 }
 extern "C" int nmf_solver_check_sums(nmf_solver *s, double sums[3]) { return check_sums_pair(s, 0, sums); }
+// every pair's three sums (KL, sum|X-WH|, sum|X|) behind one synchronisation: batch check launches back to back on the
+// stream (they share the partial buffer in stream order), one copy of 3 * batch doubles
+extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
+    if (!s) return NMF_ERR_ARG;
+    if (s->path != NMF_PATH_FUSED) { set_err("check_all: fused path only"); return NMF_ERR_UNSUPPORTED; }
+    hipStream_t st = s->stream;
+    for (int b = 0; b < s->batch; ++b) {
+        HIPCHK(launch_check(s->W + (size_t)b * s->Mp * s->Kp, s->H + (size_t)b * s->Kp * s->Np, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+        HIPCHK(launch_check_final(s->chk_part, s->chk_groups, s->chk_out + 3 * (size_t)b, st));
+    }
+    HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int b = 0; b < s->batch; ++b) {
+        const double *v = s->chk_host + 3 * (size_t)b;
+        if (kl) kl[b] = v[0];
+        if (rel_l1) rel_l1[b] = (v[2] > 0.0) ? v[1] / v[2] : 0.0;
+    }
+    return NMF_OK;
+}
 extern "C" int nmf_solver_check_pair(nmf_solver *s, int b, double *kl, double *rel_l1) {
     double v[3];
     NMFCHK(check_sums_pair(s, b, v));
@@ -1042,6 +1067,64 @@ static int auto_lanes(const nmf_solver *s, int n_restarts) {
     return lanes > n_restarts ? n_restarts : lanes;
 }
 
+// The restarts as ONE batched solver: the restart index is a grid dimension of the split kernel, so every launch carries
+// all B pairs (B x the workgroups; X tiles shared through L2), each pair iterating exactly as a sequential update_div on
+// it would -- same kernels, same split counts, hence the same bits -- and freezing at its own convergence check.
+constexpr int kMaxRestartBatch = 64;
+static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o, int M, int N, int K, int *best, double *kl) {
+    const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
+    nmf_solver *s = nullptr;
+    NMFCHK(nmf_solver_create_batched(&s, M, N, K, B, &o));
+    int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
+    const int iter_check = o.iter_check > 0 ? o.iter_check : NMF_ITER_CHECK_DEFAULT;
+    const bool checks = (o.converge_thresh > 0.f) || o.verbose;
+    std::vector<double> prev((size_t)B), cur((size_t)B), rl1((size_t)B);
+    std::vector<int> act((size_t)B);
+    int best_i = -1;
+    double best_kl = 0.0;
+    for (int base = 0; st == NMF_OK && base < n_restarts; base += B) {
+        const int n = (n_restarts - base < B) ? (n_restarts - base) : B;
+        for (int b = 0; st == NMF_OK && b < n; ++b) st = nmf_solver_upload_pair(s, b, W[base + b].mat, H[base + b].mat);
+        for (int b = 0; b < B; ++b) act[(size_t)b] = b < n;
+        if (st == NMF_OK) st = nmf_solver_set_active(s, act.data());
+        if (st == NMF_OK && checks) {
+            st = nmf_solver_check_all(s, prev.data(), rl1.data());
+            if (o.verbose) for (int b = 0; b < n; ++b) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", base + b, 0, prev[(size_t)b], rl1[(size_t)b]);
+        }
+        for (int it = 0; st == NMF_OK && it < o.max_iter;) {
+            int nstep = o.max_iter - it;
+            if (checks) { const int to_check = iter_check - (it % iter_check); if (to_check < nstep) nstep = to_check; }
+            bool any = false;
+            for (int b = 0; b < n; ++b) any = any || act[(size_t)b];
+            if (!any) break;
+            st = nmf_solver_iterate(s, nstep);
+            it += nstep;
+            if (st == NMF_OK && checks && (it % iter_check) == 0) {
+                st = nmf_solver_check_all(s, cur.data(), rl1.data());
+                bool changed = false;
+                for (int b = 0; st == NMF_OK && b < n; ++b) {
+                    if (!act[(size_t)b]) continue;
+                    const double p = prev[(size_t)b], c = cur[(size_t)b];
+                    if (o.verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", base + b, it, c, rl1[(size_t)b], (p - c) / p);
+                    if (o.converge_thresh > 0.f && (p - c) / p < (double)o.converge_thresh) { act[(size_t)b] = 0; changed = true; }   // README.md:51
+                    prev[(size_t)b] = c;
+                }
+                if (st == NMF_OK && changed) st = nmf_solver_set_active(s, act.data());
+            }
+        }
+        if (st == NMF_OK) st = nmf_solver_check_all(s, cur.data(), nullptr);
+        for (int b = 0; st == NMF_OK && b < n; ++b) {
+            st = nmf_solver_download_pair(s, b, W[base + b].mat, H[base + b].mat);
+            if (kl) kl[base + b] = cur[(size_t)b];
+            if (best_i < 0 || cur[(size_t)b] < best_kl) { best_i = base + b; best_kl = cur[(size_t)b]; }
+        }
+    }
+    if (st == NMF_OK && hipGetLastError() != hipSuccess) { set_err("update_div_restarts: a kernel launch failed"); st = NMF_ERR_HIP; }
+    nmf_solver_destroy(s);
+    if (st == NMF_OK && best) *best = best_i;
+    return st;
+}
+
 extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts_in, int *best, double *kl) {
     if (!W || !H || n_restarts < 1 || (!X.mat && !X.mat_d)) { set_err("update_div_restarts: bad arguments"); return NMF_ERR_ARG; }
     nmf_opts o;
@@ -1054,6 +1137,8 @@ extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_resta
             return NMF_ERR_SHAPE;
         }
     }
+    // restart_lanes > 0 asks for the stream-lane mechanism explicitly (the shapes the split kernel does not take use it anyway)
+    if (n_restarts > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o)) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl);
     std::vector<nmf_solver *> lane;
     nmf_solver *s0 = nullptr;
     NMFCHK(nmf_solver_create(&s0, M, N, K, &o));

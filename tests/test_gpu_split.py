@@ -1,0 +1,251 @@
+"""GPU parity of the split kernel (nmf_split16.hip: the half-step for problems that do not fill the chip, and for B restarts
+per launch) against the CPU oracle and against itself, through the C ABI.
+
+Reference semantics: update_h / update_w, cuda/nmf.cu:118-176; set_epsilon's NaN-passing clamp, cuda/matrix.cu:182-188;
+the reference's own workload 4096 x 350 x 128, matrix_export.py:4-7; multi-restart NMF, nmf_ismir_2009.pdf section 3.2.
+Tolerance: rel-Frobenius, fp32 both sides, stated per test (north_star gate: 1e-4 after 200 iterations)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _relF(oracle, a, b):
+    return oracle.relF(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 96, 32), (100, 70, 17), (257, 130, 64), (33, 1, 1), (1, 33, 5), (300, 1000, 100), (129, 257, 128), (128, 128, 65)])
+def test_split_kernel_half_steps(ng, oracle, M, N, K):
+    """one update_h then one update_w on ragged and degenerate sizes: the in-stream normalisers (colsum W, rowsum H) and
+    the four-wave reduction must reproduce the oracle; the other factor must not be touched"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=7)
+    s = ng.Solver(M, N, K, split_kernel=1, use_graph=False)
+    assert s.uses_split_kernel
+    s.upload(W, H, X)
+    s.update_h()
+    W1, H1 = s.download()
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert _relF(oracle, H1, Hr) < 5e-6 and np.array_equal(W1, oracle.clamp(W))
+    s.update_w()
+    W2, H2 = s.download()
+    Wr = oracle.update_w(oracle.clamp(W), Hr, oracle.clamp(X))
+    assert _relF(oracle, W2, Wr) < 5e-6 and np.array_equal(H2, H1)
+    s.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)])
+def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
+    """BASELINE config 2, the reference's gold shape and the paper's shape, 200 iterations (cuda/nmf.cu:10), default options
+    (automatic kernel choice = split kernel, hipGraph replay): the north_star gate is 1e-4, measured ~4e-6"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=200)
+    assert r["iterations"] == 200
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
+    eW, eH = _relF(oracle, Wm.mat, Wr), _relF(oracle, Hm.mat, Hr)
+    eWH = _relF(oracle, Wm.mat.astype(np.float64) @ Hm.mat.astype(np.float64), Wr.astype(np.float64) @ Hr.astype(np.float64))
+    assert eW < 1e-4 and eH < 1e-4 and eWH < 1e-4, (eW, eH, eWH)
+    if (M, N, K) == (4096, 350, 128):
+        # components die on this problem (17 of 128 survive in the reference's run): whole columns of W reach
+        # zero, their column sums are clamped to EPS (set_epsilon on sumW, cuda/nmf.cu:135) and the loop must carry on
+        dead = int((Wm.mat.max(axis=0) == 0).sum())
+        assert dead == int((Wr.max(axis=0) == 0).sum())
+        assert np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all()
+
+
+def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
+    for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), False),
+                            ((4096, 65536, 64), False)):
+        s = ng.Solver(M, N, K)
+        assert s.uses_split_kernel == want, (M, N, K)
+        s.close()
+    s = ng.Solver(256, 256, 64, split_kernel=-1)
+    assert not s.uses_split_kernel
+    s.close()
+
+
+@pytest.mark.parametrize("nh,nw", [(1, 1), (2, 3), (4, 1), (1, 5)])
+def test_workgroup_level_splits_only_change_summation_order(ng, oracle, nh, nw):
+    M, N, K = 700, 900, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=3)
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 10, 25)
+    s = ng.Solver(M, N, K, split_kernel=1, nsplit_h=nh, nsplit_w=nw)
+    s.upload(W, H, X)
+    s.iterate(10)
+    Wg, Hg = s.download()
+    s.close()
+    assert _relF(oracle, Wg, Wr) < 1e-5 and _relF(oracle, Hg, Hr) < 1e-5
+
+
+def test_graph_replay_equals_eager_and_runs_are_reproducible(ng, oracle):
+    M, N, K = 1000, 777, 100
+    X, W, H = oracle.gen_problem(M, N, K, seed=4)
+    outs = []
+    for graph in (True, False, True):
+        s = ng.Solver(M, N, K, split_kernel=1, use_graph=graph)
+        s.upload(W, H, X)
+        s.iterate(19)     # 2 x 8 captured iterations + 3 single ones on the graph path
+        outs.append(s.download())
+        s.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+def test_resume_from_downloaded_factors_equals_uninterrupted_run(ng, oracle):
+    """the split kernel's normalisers are a function of the factor it streams: no state is handed between launches"""
+    M, N, K = 640, 1100, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=5)
+    s = ng.Solver(M, N, K, split_kernel=1)
+    s.upload(W, H, X)
+    s.iterate(12)
+    Wa, Ha = s.download()
+    s.upload(W, H, X)
+    s.iterate(5)
+    Wm, Hm = s.download()
+    s.upload(Wm, Hm)
+    s.iterate(7)
+    Wb, Hb = s.download()
+    s.close()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+
+
+@pytest.mark.parametrize("M,N,K,B", [(1024, 512, 64, 5), (512, 350, 128, 3)])
+def test_batched_pairs_equal_single_solvers_bit_for_bit(ng, oracle, M, N, K, B):
+    """B (W, H) pairs per launch (blockIdx.y) against one resident X: every pair must come out exactly as a solver of its
+    own would produce it; frozen pairs (set_active) must not move"""
+    X, _, _ = oracle.gen_problem(M, N, K, seed=6)
+    rng = np.random.default_rng(11)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(B)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(B)]
+    single = []
+    for w, h in zip(Ws, Hs):
+        s = ng.Solver(M, N, K)
+        assert s.uses_split_kernel
+        s.upload(w, h, X)
+        s.iterate(9)
+        w9, h9 = s.download()
+        kl9 = s.check()[0]
+        s.iterate(6)
+        single.append((w9, h9, kl9) + s.download())
+        s.close()
+    sb = ng.Solver(M, N, K, batch=B)
+    sb.upload(None, None, X)
+    for b in range(B):
+        sb.upload_pair(b, Ws[b], Hs[b])
+    sb.iterate(9)
+    kls, _ = sb.check_all()
+    for b in range(B):
+        wb, hb = sb.download_pair(b)
+        assert np.array_equal(wb, single[b][0]) and np.array_equal(hb, single[b][1]) and kls[b] == single[b][2]
+        assert sb.check_pair(b)[0] == kls[b]
+    frozen = [b % 2 == 0 for b in range(B)]           # even pairs keep iterating, odd pairs are frozen
+    sb.set_active(frozen)
+    sb.iterate(6)
+    for b in range(B):
+        wb, hb = sb.download_pair(b)
+        ref = single[b][3:5] if frozen[b] else single[b][0:2]
+        assert np.array_equal(wb, ref[0]) and np.array_equal(hb, ref[1]), b
+    sb.close()
+
+
+@pytest.mark.parametrize("M,N,K,R,thresh", [(1024, 1024, 64, 6, 0.0), (1024, 350, 128, 4, 0.0), (512, 1000, 30, 7, 2e-3)])
+def test_batched_restarts_equal_sequential_update_div_bit_for_bit(ng, oracle, M, N, K, R, thresh):
+    """update_div_restarts on a shape the split kernel takes: one batched solver, every launch carries all restarts; each
+    restart must equal a plain update_div_ex of that pair -- factors, final KL, and the iteration it stopped at"""
+    X, _, _ = oracle.gen_problem(M, N, K, seed=8)
+    rng = np.random.default_rng(13)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=60, converge_thresh=thresh, iter_check=10)
+    seq_kl = []
+    for i in range(R):
+        w1, h1 = ng.Matrix(Ws[i].copy(order="F")), ng.Matrix(Hs[i].copy(order="F"))
+        r = ng.update_div_ex(w1, h1, ng.Matrix(X), max_iter=60, converge_thresh=thresh, iter_check=10)
+        assert np.array_equal(w1.mat, Wm[i].mat) and np.array_equal(h1.mat, Hm[i].mat), i
+        s = ng.Solver(M, N, K)
+        s.upload(w1.mat, h1.mat, X)
+        seq_kl.append(s.check()[0])
+        s.close()
+        if thresh > 0:
+            assert r["iterations"] <= 60
+    assert kls == seq_kl and best == int(np.argmin(seq_kl))
+    # and against the oracle, one pair
+    wr, hr, _, _ = oracle.update_div(Ws[1], Hs[1], X, thresh, 60, 10)
+    assert _relF(oracle, Wm[1].mat, wr) < 2e-5 and _relF(oracle, Hm[1].mat, hr) < 2e-5
+
+
+@pytest.mark.parametrize("split_kernel", [1, -1])
+@pytest.mark.parametrize("where", ["X", "W", "H"])
+def test_nan_in_an_input_spreads_exactly_as_in_the_reference_arithmetic(ng, oracle, split_kernel, where):
+    """set_epsilon is a clamp that lets NaN through (cuda/matrix.cu:185-186: `a < EPS` is false for NaN), so a NaN entry
+    poisons what the reference's arithmetic says it poisons -- one column of H after update_h, then all of W -- and nothing
+    else; no hang, no spurious NaN from the range-guarded quotient (which must fall back to the full IEEE sequence)"""
+    M, N, K = 200, 330, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=12)
+    X, W, H = X.copy(order="F"), W.copy(order="F"), H.copy(order="F")
+    {"X": X, "W": W, "H": H}[where][5, 7] = np.nan
+    s = ng.Solver(M, N, K, split_kernel=split_kernel, use_graph=False)
+    s.upload(W, H, X)
+    s.update_h()
+    W1, H1 = s.download()
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert np.array_equal(np.isnan(H1), np.isnan(Hr))
+    ok = ~np.isnan(Hr)
+    assert np.isnan(Hr).any() and (where == "W" or ok.sum() == K * (N - 1))    # X or H: exactly column 7 of H; W: W*H is NaN in row 5 of every column
+    if ok.any():
+        assert _relF(oracle, H1[ok], Hr[ok]) < 5e-6
+    s.update_w()
+    W2, _ = s.download()
+    Wr = oracle.update_w(oracle.clamp(W), Hr, oracle.clamp(X))
+    assert np.array_equal(np.isnan(W2), np.isnan(Wr)) and np.isnan(W2).any()
+    ok = ~np.isnan(Wr)
+    if ok.any():
+        assert _relF(oracle, W2[ok], Wr[ok]) < 5e-6
+    s.iterate(3)      # and a poisoned loop terminates
+    s.sync()
+    s.close()
+
+
+@pytest.mark.parametrize("split_kernel", [1, -1])
+def test_huge_and_tiny_entries_of_x_in_one_wave(ng, oracle, split_kernel):
+    """X entries far outside the range the short quotient is proven for (> 2^60, and subnormal inputs, which the upload
+    clamp raises to EPS, cuda/nmf.cu:211) next to ordinary ones, in the same 16 x 32 tile: the upload-time range check
+    must send the whole run through the full IEEE division and the result must match the oracle"""
+    M, N, K = 256, 384, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=14)
+    X = X.copy(order="F")
+    X[0, 0], X[1, 0], X[2, 0], X[3, 1] = 3e30, 1e-40, 0.0, 1e25
+    s = ng.Solver(M, N, K, split_kernel=split_kernel)
+    s.upload(W, H, X)
+    s.iterate(5)
+    Wg, Hg = s.download()
+    s.close()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 5, 25)
+    assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
+    assert _relF(oracle, Wg, Wr) < 1e-5 and _relF(oracle, Hg, Hr) < 1e-5
+
+
+def test_update_div_accepts_numpy_arrays_and_updates_them_in_place(ng, oracle):
+    """the Python mirror of update_div(W, H, X, ...) (README.md:40-54): W and H are in/out -- also when they are plain
+    ndarrays (Fortran or C order), which the binding copies into a column-major Matrix and back"""
+    M, N, K = 128, 200, 16
+    X, W, H = oracle.gen_problem(M, N, K, seed=15)
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 10, 25)
+    for order in ("F", "C"):
+        Wa, Ha = np.array(W, order=order), np.array(H, order=order)
+        ng.update_div(Wa, Ha, X, 0.0, 10, None, 0)
+        assert _relF(oracle, Wa, Wr) < 1e-5 and _relF(oracle, Ha, Hr) < 1e-5
+        Wb, Hb = np.array(W, order=order), np.array(H, order=order)
+        r = ng.update_div_ex(Wb, Hb, X, max_iter=10)
+        assert r["iterations"] == 10 and np.array_equal(Wb, Wa) and np.array_equal(Hb, Ha)
+    Wl = [np.array(W, order="F"), np.array(W[:, ::-1], order="F")]
+    Hl = [np.array(H, order="F"), np.array(H[::-1, :], order="F")]
+    best, kls = ng.update_div_restarts(Wl, Hl, X, max_iter=10)
+    assert _relF(oracle, Wl[0], Wr) < 1e-5 and not np.array_equal(Wl[1], W[:, ::-1])
+    with pytest.raises(TypeError):
+        ng.update_div(W.tolist(), H, X, 0.0, 1, None, 0)
+    ro = np.array(W, order="F")
+    ro.setflags(write=False)
+    with pytest.raises(TypeError):
+        ng.update_div(ro, H, X, 0.0, 1, None, 0)
