@@ -110,6 +110,14 @@ typedef struct {
     int   split_kernel;     /* which fused kernel family: 0 = automatic; 1 = the split kernel (four waves per 16 owned columns,
                              * normalisers summed in-stream, two to four launches per iteration: problems that do not fill
                              * the chip, K <= 128); -1 = never (the 64-column kernel of the large configurations) */
+    int   n_devices;        /* update_div / update_div_ex with host matrices: how many GPUs of this node share the work (columns of
+                             * X and H are sharded, W is replicated, one RCCL all-reduce of [Z*H' ; rowsum(H)] per iteration inside
+                             * each device's hipGraph; one host thread per device, all inside the call).  0 = automatic: every visible
+                             * device when the problem is large enough to amortise the all-reduce (nmf_worth_sharding; the
+                             * environment variable NMF_DEVICES=<n>|all overrides), else one; 1 = one; n > 1 = exactly n */
+    const int *devices;     /* optional list of n_devices HIP ordinals; NULL = device, device + 1, ... (device < 0: from 0) */
+    int   emulate_shards;   /* G > 1: run the multi-device driver with G ranks on ONE device, the all-reduce replaced by a
+                             * device-side sum in rank order (for one-GPU test boxes; at most 8) */
 } nmf_opts;
 
 #define NMF_MAX_KL 64
@@ -120,6 +128,8 @@ typedef struct {
     double rel_l1;              /* sum|X-WH| / sum|X| at the last check (cuda/matrix.cu:517-518) */
     int    path_used;
     double t[10];
+    int    n_shards;            /* ranks the columns were sharded over (1 = single GPU) */
+    int    w_replicas_identical;/* sharded runs: 1 if every rank ended with bit-identical W (it must), else 0; single GPU: 1 */
 } nmf_result;
 
 void nmf_default_opts(nmf_opts *o);
@@ -246,6 +256,9 @@ typedef struct nmf_comm nmf_comm;
 int  nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]);
 int  nmf_comm_init_rank(nmf_comm **c, const unsigned char id[NMF_COMM_ID_BYTES], int rank, int nranks);
 void nmf_comm_destroy(nmf_comm *c);
+
+/* 1 if sharding an M x N x K problem over n_devices GPUs amortises the per-iteration all-reduce (what n_devices = 0 uses) */
+int  nmf_worth_sharding(int M, int N, int K, int n_devices);
 
 /* device queries used by bench/tests */
 int  nmf_device_count(void);

@@ -49,12 +49,14 @@ class _opts(C.Structure):
     _fields_ = [("converge_thresh", C.c_float), ("max_iter", C.c_int), ("iter_check", C.c_int),
                 ("verbose", C.c_int), ("path", C.c_int), ("use_graph", C.c_int), ("device", C.c_int),
                 ("stream", C.c_void_p), ("comm", C.c_void_p), ("nsplit_h", C.c_int), ("nsplit_w", C.c_int),
-                ("fast_divide", C.c_int), ("restart_lanes", C.c_int), ("split_kernel", C.c_int)]
+                ("fast_divide", C.c_int), ("restart_lanes", C.c_int), ("split_kernel", C.c_int),
+                ("n_devices", C.c_int), ("devices", C.POINTER(C.c_int)), ("emulate_shards", C.c_int)]
 
 
 class _result(C.Structure):
     _fields_ = [("iterations", C.c_int), ("n_kl", C.c_int), ("kl", C.c_double * NMF_MAX_KL),
-                ("rel_l1", C.c_double), ("path_used", C.c_int), ("t", C.c_double * 10)]
+                ("rel_l1", C.c_double), ("path_used", C.c_int), ("t", C.c_double * 10),
+                ("n_shards", C.c_int), ("w_replicas_identical", C.c_int)]
 
 
 # every symbol include/nmf_mi355x.h declares: (name, restype, argtypes)
@@ -116,6 +118,7 @@ _SIGS = [
     ("nmf_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("nmf_comm_init_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
     ("nmf_comm_destroy", None, [C.c_void_p]),
+    ("nmf_worth_sharding", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("nmf_device_count", C.c_int, []),
     ("nmf_device_name", C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     ("nmf_version", C.c_char_p, []),
@@ -276,7 +279,8 @@ def _make_opts(**kw) -> _opts:
 
 def _result_dict(r: _result) -> dict:
     return {"iterations": int(r.iterations), "kl": [float(r.kl[i]) for i in range(r.n_kl)],
-            "rel_l1": float(r.rel_l1), "path_used": int(r.path_used),
+            "rel_l1": float(r.rel_l1), "path_used": int(r.path_used), "n_shards": int(r.n_shards),
+            "w_replicas_identical": int(r.w_replicas_identical),
             "t": {T_NAMES[i]: float(r.t[i]) for i in range(10)}}
 
 

@@ -16,6 +16,7 @@ static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--X f] [--W f] [--H f] [--Wout f] [--Hout f] [--iters n] [--thresh x]\n"
             "          [--check n] [--verbose] [--timers] [--path auto|fused|unfused] [--device d]\n"
+            "          [--devices n] (GPUs to shard the columns over; default: all when the problem is large enough)\n"
             "       %s generate [--M m] [--N n] [--K k] [--seed s] [--X f] [--W f] [--H f]\n"
             "       %s compare A.bin B.bin [--tol t]\n"
             "defaults follow cuda/nmf.cu:9-11,37-45: ../X.bin ../W.bin ../H.bin -> ../Wout.bin ../Hout.bin,\n"
@@ -129,6 +130,8 @@ int main(int argc, char **argv) {
         else if (a == "--check") o.iter_check = atoi(next());
         else if (a == "--verbose") o.verbose = 1;
         else if (a == "--timers") timers = true;
+        else if (a == "--devices") o.n_devices = atoi(next());
+        else if (a == "--emulate-shards") o.emulate_shards = atoi(next());
         else if (a == "--device") o.device = atoi(next());
         else if (a == "--path") {
             const std::string p = next();

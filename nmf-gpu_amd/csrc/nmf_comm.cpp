@@ -5,24 +5,27 @@
 #include "../../include/nmf_mi355x.h"
 
 #include <dlfcn.h>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+// Types, enums and prototypes come from the RCCL header (compile time only: the library itself is dlopen()ed on first use,
+// so single-GPU users of libnmf_mi355x.so never load it); the function-pointer table below is checked against the header's
+// prototypes by the decltype casts in load_api().
+#include <rccl/rccl.h>
 
 namespace {
-// minimal RCCL ABI (rccl.h): opaque comm, 128-byte unique id, enums as ints
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclFloat32 = 7, ncclFloat64 = 8 };   // ncclDataType_t
-enum { ncclSum = 0 };                        // ncclRedOp_t
-
 struct Api {
     void *handle = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
 };
 Api g_api;
@@ -35,20 +38,62 @@ bool load_api() {
         if (g_api.handle) break;
     }
     if (!g_api.handle) { fprintf(stderr, "nmf_comm: cannot dlopen librccl: %s\n", dlerror()); return false; }
-    g_api.GetUniqueId = (int (*)(ncclUniqueId *))dlsym(g_api.handle, "ncclGetUniqueId");
-    g_api.CommInitRank = (int (*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(g_api.handle, "ncclCommInitRank");
-    g_api.CommDestroy = (int (*)(ncclComm_t))dlsym(g_api.handle, "ncclCommDestroy");
-    g_api.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))dlsym(g_api.handle, "ncclAllReduce");
-    g_api.GetErrorString = (const char *(*)(int))dlsym(g_api.handle, "ncclGetErrorString");
+    g_api.GetUniqueId = (decltype(&ncclGetUniqueId))dlsym(g_api.handle, "ncclGetUniqueId");
+    g_api.CommInitRank = (decltype(&ncclCommInitRank))dlsym(g_api.handle, "ncclCommInitRank");
+    g_api.CommInitAll = (decltype(&ncclCommInitAll))dlsym(g_api.handle, "ncclCommInitAll");
+    g_api.CommDestroy = (decltype(&ncclCommDestroy))dlsym(g_api.handle, "ncclCommDestroy");
+    g_api.AllReduce = (decltype(&ncclAllReduce))dlsym(g_api.handle, "ncclAllReduce");
+    g_api.GetErrorString = (decltype(&ncclGetErrorString))dlsym(g_api.handle, "ncclGetErrorString");
     g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce;
     return g_api.ok;
 }
 }  // namespace
 
+// A same-device group: `n` shards of one problem on ONE GPU, each driven by its own host thread and stream, with the
+// all-reduce done by a device kernel behind two host rendezvous.  It exists so that the multi-device driver (nmf_multi.cpp:
+// threads, column shards, W broadcast, per-rank loop, H gather) can be run and checked on a one-GPU box; the arithmetic is
+// the all-reduce's contract, sum over ranks in rank order, so every rank ends up with the same bits.
+constexpr int kMaxEmu = 8;
+struct EmuGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long generation = 0;
+    const void *buf[kMaxEmu] = {};
+    hipEvent_t ev1[kMaxEmu] = {}, ev2[kMaxEmu] = {};
+    void *tmp[kMaxEmu] = {};
+    size_t tmp_bytes[kMaxEmu] = {};
+    ~EmuGroup() {
+        for (int i = 0; i < n; ++i) {
+            if (ev1[i]) (void)hipEventDestroy(ev1[i]);
+            if (ev2[i]) (void)hipEventDestroy(ev2[i]);
+            if (tmp[i]) (void)hipFree(tmp[i]);
+        }
+    }
+    void rendezvous() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
 struct nmf_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    std::shared_ptr<EmuGroup> emu;   // set: a same-device emulated group instead of an RCCL communicator
 };
+
+struct EmuPtrs { const void *p[kMaxEmu]; };
+template <typename T>
+__global__ __launch_bounds__(256) void emu_sum_kernel(EmuPtrs src, int n, T *__restrict__ dst, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        T s = reinterpret_cast<const T *>(src.p[0])[i];
+        for (int r = 1; r < n; ++r) s += reinterpret_cast<const T *>(src.p[r])[i];   // rank order: the same bits on every rank
+        dst[i] = s;
+    }
+}
 
 extern "C" int nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]) {
     if (!id) return NMF_ERR_ARG;
@@ -67,7 +112,7 @@ extern "C" int nmf_comm_init_rank(nmf_comm **out, const unsigned char id[NMF_COM
     memcpy(&u, id, sizeof u);
     nmf_comm *c = new nmf_comm();
     c->rank = rank; c->nranks = nranks;
-    const int rc = g_api.CommInitRank(&c->comm, nranks, u, rank);
+    const ncclResult_t rc = g_api.CommInitRank(&c->comm, nranks, u, rank);
     if (rc != ncclSuccess) {
         fprintf(stderr, "nmf_comm: ncclCommInitRank failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
         delete c;
@@ -83,12 +128,77 @@ extern "C" void nmf_comm_destroy(nmf_comm *c) {
     delete c;
 }
 
+// ncclCommInitAll: one process drives n devices (devices[i] = HIP ordinal of rank i), one host thread per rank afterwards
+int nmf_comm_init_all(nmf_comm **out, int n, const int *devices) {
+    if (!out || n < 1 || !devices) return NMF_ERR_ARG;
+    if (!load_api() || !g_api.CommInitAll) return NMF_ERR_COMM;
+    std::vector<ncclComm_t> cs((size_t)n, nullptr);
+    const ncclResult_t rc = g_api.CommInitAll(cs.data(), n, devices);
+    if (rc != ncclSuccess) {
+        fprintf(stderr, "nmf_comm: ncclCommInitAll failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
+        return NMF_ERR_COMM;
+    }
+    for (int i = 0; i < n; ++i) {
+        out[i] = new nmf_comm();
+        out[i]->comm = cs[(size_t)i]; out[i]->rank = i; out[i]->nranks = n;
+    }
+    return NMF_OK;
+}
+
+// n emulated ranks on the current device (see EmuGroup)
+int nmf_comm_create_emulated(nmf_comm **out, int n) {
+    if (!out || n < 1 || n > kMaxEmu) return NMF_ERR_ARG;
+    auto g = std::make_shared<EmuGroup>();
+    g->n = n;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventCreateWithFlags(&g->ev1[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev2[i], hipEventDisableTiming) != hipSuccess)
+            return NMF_ERR_HIP;
+    }
+    for (int i = 0; i < n; ++i) {
+        out[i] = new nmf_comm();
+        out[i]->rank = i; out[i]->nranks = n; out[i]->emu = g;
+    }
+    return NMF_OK;
+}
+bool nmf_comm_capturable(const nmf_comm *c) { return c && !c->emu; }
+
+template <typename T>
+static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) {
+    EmuGroup &g = *c->emu;
+    const int r = c->rank, n = g.n;
+    const size_t bytes = count * sizeof(T);
+    if (g.tmp_bytes[r] < bytes) {
+        if (g.tmp[r]) (void)hipFree(g.tmp[r]);
+        g.tmp[r] = nullptr; g.tmp_bytes[r] = 0;
+        if (hipMalloc(&g.tmp[r], bytes) != hipSuccess) return NMF_ERR_NOMEM;
+        g.tmp_bytes[r] = bytes;
+    }
+    g.buf[r] = buf;
+    if (hipEventRecord(g.ev1[r], stream) != hipSuccess) return NMF_ERR_HIP;
+    g.rendezvous();                                    // every operand is enqueued and published
+    EmuPtrs ptrs;
+    for (int h = 0; h < n; ++h) {
+        ptrs.p[h] = g.buf[h];
+        if (h != r && hipStreamWaitEvent(stream, g.ev1[h], 0) != hipSuccess) return NMF_ERR_HIP;
+    }
+    size_t grid = (count + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(emu_sum_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (T *)g.tmp[r], count);
+    if (hipEventRecord(g.ev2[r], stream) != hipSuccess) return NMF_ERR_HIP;
+    g.rendezvous();                                    // every rank has read every operand ...
+    for (int h = 0; h < n; ++h)
+        if (h != r && hipStreamWaitEvent(stream, g.ev2[h], 0) != hipSuccess) return NMF_ERR_HIP;
+    if (hipMemcpyAsync(buf, g.tmp[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return NMF_ERR_HIP;   // ... before any is overwritten
+    return NMF_OK;
+}
+
 int nmf_comm_rank(const nmf_comm *c) { return c ? c->rank : 0; }
 int nmf_comm_size(const nmf_comm *c) { return c ? c->nranks : 1; }
 
-static int allreduce(nmf_comm *c, void *buf, size_t count, int dtype, hipStream_t stream) {
+static int allreduce(nmf_comm *c, void *buf, size_t count, ncclDataType_t dtype, hipStream_t stream) {
+    if (c && c->emu) return dtype == ncclFloat32 ? emu_allreduce(c, (float *)buf, count, stream) : emu_allreduce(c, (double *)buf, count, stream);
     if (!c || !c->comm) return NMF_ERR_ARG;
-    const int rc = g_api.AllReduce(buf, buf, count, dtype, ncclSum, c->comm, stream);
+    const ncclResult_t rc = g_api.AllReduce(buf, buf, count, dtype, ncclSum, c->comm, stream);
     if (rc != ncclSuccess) {
         fprintf(stderr, "nmf_comm: ncclAllReduce failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
         return NMF_ERR_COMM;

@@ -10,3 +10,9 @@ int nmf_comm_allreduce_f32(nmf_comm *c, float *buf, size_t count, hipStream_t st
 int nmf_comm_allreduce_f64(nmf_comm *c, double *buf, size_t count, hipStream_t stream);
 int nmf_comm_rank(const nmf_comm *c);
 int nmf_comm_size(const nmf_comm *c);
+// one process, n devices (ncclCommInitAll); one host thread per rank must then drive its communicator
+int nmf_comm_init_all(nmf_comm **comms, int n, const int *devices);
+// n emulated ranks on the current device: host-thread rendezvous + a device-side sum in rank order (one-GPU test boxes)
+int nmf_comm_create_emulated(nmf_comm **comms, int n);
+// can the collective be captured into a hipGraph? (RCCL: yes; the emulated group needs its host rendezvous: no)
+bool nmf_comm_capturable(const nmf_comm *c);

@@ -84,6 +84,9 @@ extern "C" void nmf_default_opts(nmf_opts *o) {
     o->fast_divide = 0;
     o->restart_lanes = 0;
     o->split_kernel = 0;
+    o->n_devices = 0;
+    o->devices = nullptr;
+    o->emulate_shards = 0;
 }
 
 static double now_s() {
@@ -974,6 +977,41 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
 }
 
 // ------------------------------------------------------------------------------ update_div
+int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const int *devices, int G, bool emulate, nmf_result *res);   // nmf_multi.cpp
+
+// How many ranks, on which devices: nmf_opts.n_devices / devices / emulate_shards, NMF_DEVICES, nmf_worth_sharding
+static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, const matrix &X, int M, int N, int K,
+                        std::vector<int> &devices, bool &emulate, bool &automatic) {
+    devices.clear(); emulate = false; automatic = false;
+    const bool host_data = W.mat && H.mat && X.mat;
+    if (o.emulate_shards > 1) {
+        if (o.emulate_shards > 8 || !host_data || o.comm || o.stream || N < o.emulate_shards) { set_err("emulate_shards: needs host matrices, at most 8 ranks, N >= ranks, no caller stream or communicator"); return NMF_ERR_ARG; }
+        int cur = 0;
+        if (o.device >= 0) cur = o.device; else HIPCHK(hipGetDevice(&cur));
+        devices.assign((size_t)o.emulate_shards, cur);
+        emulate = true;
+        return NMF_OK;
+    }
+    int want = o.n_devices;
+    if (want == 1 || want < 0) return NMF_OK;
+    if (o.comm || o.stream || !host_data) {
+        if (want > 1) { set_err("n_devices > 1 needs host matrices and no caller stream or communicator"); return NMF_ERR_ARG; }
+        return NMF_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    if (want == 0) {
+        const char *e = getenv("NMF_DEVICES");
+        if (e && e[0]) want = (strcmp(e, "all") == 0) ? ndev : atoi(e);
+        else { want = (ndev > 1 && nmf_worth_sharding(M, N, K, ndev)) ? ndev : 1; automatic = true; }
+        if (want <= 1) return NMF_OK;
+    }
+    const int base = o.devices ? 0 : (o.device >= 0 ? o.device : 0);
+    if (want > N || (!o.devices && base + want > ndev)) { set_err("n_devices = %d: only %d devices visible from ordinal %d (N = %d)", want, ndev, base, N); return NMF_ERR_ARG; }
+    for (int g = 0; g < want; ++g) devices.push_back(o.devices ? o.devices[g] : base + g);
+    return NMF_OK;
+}
+
 extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_in, nmf_result *res) {
     const double t_begin = now_s();
     nmf_opts o;
@@ -988,6 +1026,19 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
     nmf_result local;
     if (!res) res = &local;
     memset(res, 0, sizeof *res);
+    res->n_shards = 1; res->w_replicas_identical = 1;
+    {
+        std::vector<int> devices;
+        bool emulate = false, automatic = false;
+        NMFCHK(plan_devices(o, W, H, X, M, N, K, devices, emulate, automatic));
+        if (devices.size() > 1) {
+            const int st = nmf_update_div_multi(W, H, X, o, devices.data(), (int)devices.size(), emulate, res);
+            if (!(st == NMF_ERR_COMM && automatic)) return st;
+            fprintf(stderr, "nmf: no RCCL communicator over %d devices; running on one GPU\n", (int)devices.size());
+            memset(res, 0, sizeof *res);
+            res->n_shards = 1; res->w_replicas_identical = 1;
+        }
+    }
     nmf_solver *s = nullptr;
     NMFCHK(nmf_solver_create(&s, M, N, K, &o));
     int st = NMF_OK;

@@ -1,0 +1,136 @@
+// nmf_multi.cpp -- update_div over the GPUs of one node, inside the library (SURVEY 8b "Threading": multi-GPU is
+// callee-internal, invisible at the boundary): ONE process, one host thread per device, column shards of X and H,
+// a full copy of W everywhere, and per iteration one RCCL all-reduce of [Z_g*H_g' ; rowsum(H_g)] captured inside each
+// device's hipGraph.  No Python, no torch: the caller is the reference's plain `main` (cuda/nmf.cu:30-51).
+//
+// Each rank runs the ordinary resident solver (nmf_solver_*, nmf_host.cpp) with nmf_opts.comm set; this file only shards,
+// spawns, and gathers.  With nmf_opts.emulate_shards = G the G ranks live on ONE device and the all-reduce is a device-side
+// sum behind host rendezvous (nmf_comm.cpp: EmuGroup) -- the same driver, testable on a one-GPU box.
+#include "../../include/nmf_mi355x.h"
+#include "nmf_comm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Rank {
+    int status = NMF_OK;
+    char err[512] = "";
+    nmf_result res;
+    std::vector<float> w_copy;   // every rank's W after the run (replica check)
+};
+
+// All ranks meet here after their set-up; if any failed, every rank learns of it and none enters the loop (a rank that
+// returned early would leave the others waiting inside a collective).
+struct SetupGate {
+    std::mutex mu; std::condition_variable cv; int n, arrived = 0; bool failed = false;
+    explicit SetupGate(int n_) : n(n_) {}
+    bool pass(bool ok) {   // returns true if every rank is ok
+        std::unique_lock<std::mutex> lk(mu);
+        if (!ok) failed = true;
+        if (++arrived == n) cv.notify_all(); else cv.wait(lk, [&] { return arrived == n; });
+        return !failed;
+    }
+};
+
+// contiguous column blocks; the first N % G ranks get one more column (sharded.py: column_shards)
+void column_shards(int N, int G, std::vector<int> &start, std::vector<int> &count) {
+    start.resize((size_t)G); count.resize((size_t)G);
+    const int base = N / G, extra = N % G;
+    int s = 0;
+    for (int g = 0; g < G; ++g) { count[(size_t)g] = base + (g < extra ? 1 : 0); start[(size_t)g] = s; s += count[(size_t)g]; }
+}
+
+}  // namespace
+
+// "only where N is large enough to amortise the all-reduce" (north_star): per-GPU compute of an iteration at ~1e14 flop/s
+// against 2 x 4 (M K + K) bytes at ~1e11 B/s per xGMI link plus ~20 us of latency; shard when compute >= 4 x that
+extern "C" int nmf_worth_sharding(int M, int N, int K, int n_devices) {
+    if (n_devices <= 1 || N < n_devices) return 0;
+    const double compute_s = 8.0 * M * ((double)N / n_devices) * K / 1.0e14;
+    const double comm_s = 2.0 * 4.0 * ((double)M * K + K) / 1.0e11 + 20e-6;
+    return compute_s >= 4.0 * comm_s ? 1 : 0;
+}
+
+int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const int *devices, int G, bool emulate, nmf_result *res) {
+    const double t_begin = now_s();
+    const int M = W.dim[0], K = W.dim[1], N = H.dim[1];
+    std::vector<int> start, count;
+    column_shards(N, G, start, count);
+    std::vector<nmf_comm *> comm((size_t)G, nullptr);
+    if (emulate && hipSetDevice(devices[0]) != hipSuccess) return NMF_ERR_HIP;
+    const int cst = emulate ? nmf_comm_create_emulated(comm.data(), G) : nmf_comm_init_all(comm.data(), G, devices);
+    if (cst != NMF_OK) return cst;
+    std::vector<Rank> rank((size_t)G);
+    std::vector<std::thread> th;
+    SetupGate gate(G);
+    const double t_setup = now_s() - t_begin;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g]() {
+            Rank &r = rank[(size_t)g];
+            memset(&r.res, 0, sizeof r.res);
+            auto fail = [&](int st) { r.status = st; snprintf(r.err, sizeof r.err, "rank %d: %s", g, nmf_last_error()); };
+            if (hipSetDevice(devices[g]) != hipSuccess) { r.status = NMF_ERR_HIP; snprintf(r.err, sizeof r.err, "rank %d: hipSetDevice(%d) failed", g, devices[g]); }
+            nmf_opts og = o;
+            og.device = devices[g];
+            og.comm = comm[(size_t)g];
+            og.stream = nullptr;
+            og.n_devices = 1; og.emulate_shards = 0;
+            og.verbose = (g == 0) ? o.verbose : 0;
+            if (!nmf_comm_capturable(comm[(size_t)g])) og.use_graph = 0;
+            nmf_solver *s = nullptr;
+            int st = r.status;
+            const double t0 = now_s();
+            if (st == NMF_OK) st = nmf_solver_create(&s, M, count[(size_t)g], K, &og);
+            // W is broadcast once (every rank uploads the same host copy); H and X by column block: column-major, so a block is contiguous
+            if (st == NMF_OK) st = nmf_solver_upload(s, W.mat, H.mat + (size_t)start[(size_t)g] * K, X.mat + (size_t)start[(size_t)g] * M);
+            if (st == NMF_OK) st = nmf_solver_sync(s);
+            r.res.t[NMF_T_H2D] = now_s() - t0;
+            if (st != NMF_OK) fail(st);
+            if (!gate.pass(st == NMF_OK)) { if (s) nmf_solver_destroy(s); if (r.status == NMF_OK) { r.status = NMF_ERR_COMM; snprintf(r.err, sizeof r.err, "rank %d: another rank failed during set-up", g); } return; }
+            nmf_result rr;
+            st = nmf_solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, og.verbose, &rr);
+            if (st != NMF_OK) { fail(st); nmf_solver_destroy(s); return; }
+            const double t1 = now_s();
+            r.w_copy.resize((size_t)M * K);
+            st = nmf_solver_download(s, r.w_copy.data(), H.mat + (size_t)start[(size_t)g] * K);   // H is gathered at the end
+            const double h2d = r.res.t[NMF_T_H2D];
+            r.res = rr;
+            r.res.t[NMF_T_H2D] = h2d;
+            r.res.t[NMF_T_D2H] = now_s() - t1;
+            if (st != NMF_OK) fail(st);
+            nmf_solver_destroy(s);
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; ++g) nmf_comm_destroy(comm[(size_t)g]);
+    int st = NMF_OK;
+    for (int g = 0; g < G && st == NMF_OK; ++g)
+        if (rank[(size_t)g].status != NMF_OK) { st = rank[(size_t)g].status; fprintf(stderr, "nmf: %s\n", rank[(size_t)g].err); }
+    if (st != NMF_OK) return st;
+    // every rank applied the same update to the same all-reduced operand: the replicas of W must agree bit for bit
+    int identical = 1;
+    for (int g = 1; g < G; ++g)
+        if (memcmp(rank[(size_t)g].w_copy.data(), rank[0].w_copy.data(), sizeof(float) * (size_t)M * K) != 0) identical = 0;
+    memcpy(W.mat, rank[0].w_copy.data(), sizeof(float) * (size_t)M * K);
+    if (res) {
+        *res = rank[0].res;
+        res->n_shards = G;
+        res->w_replicas_identical = identical;
+        res->t[NMF_T_SETUP] += t_setup;
+        res->t[NMF_T_TOTAL] = now_s() - t_begin;
+    }
+    if (!identical) { fprintf(stderr, "nmf: the replicas of W differ between shards\n"); return NMF_ERR_COMM; }
+    return NMF_OK;
+}
