@@ -36,6 +36,12 @@ __device__ __forceinline__ float clamp_eps(float v) { return (v < kEps) ? kEps :
 // operands in [EPS, 2^60] (or a zero numerator) never trigger the range scaling of the IEEE division sequence
 constexpr float kDivSafeMax = 1152921504606846976.0f;   // 2^60
 
+// v_log_f32: log2 to 1 ulp in one quarter-rate instruction.  The check kernels sum x * log2(y) with it and the factor ln 2 is
+// applied once, in fp64, by check_compose_kernel: a one-ulp error per term, even if it were all bias, moves sum x log y by
+// 6e-8 of itself, i.e. the KL value by < 1e-6 relative while KL >= 6 % of sum |x log y| (every run of the tests: 15 %..300 %);
+// libm-accurate logf costs ~20 VALU instructions per element on a datapath the f32 MFMA shares.
+__device__ __forceinline__ float log2_hw(float y) { return __builtin_amdgcn_logf(y); }
+
 // 64-lane sum, result valid in lane 0
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

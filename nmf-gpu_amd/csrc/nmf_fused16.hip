@@ -182,12 +182,14 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     const int en = e + D;
                     ar[e % D] = lds_ld(b1 + (64 * ((en >> 1) >> 4) + ((en >> 1) & 15)) * kLdv + 16 * (en & 1));
                 }
-                if (GEMM) {
+                if (GEMM || CHECK) {
                     // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
                     // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: exactly 4*NST)
-                    constexpr int GL = (E1 / 2) / (NST + 1);
-                    if (e >= GL && e % GL == 0 && e / GL - 1 < NST) {
-                        stage_load_one(e / GL - 1);
+                    constexpr int NLD = GEMM ? NST : NST + 2;   // the check also fetches the next X tile (first: it is used first)
+                    constexpr int GL = (E1 / 2) / (NLD + 1);
+                    if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {
+                        const int l = e / GL - 1;
+                        if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (e >= E1 / 2 && (e - E1 / 2) % 2 == 0 && (e - E1 / 2) / 2 < 4 * NST) {
@@ -212,16 +214,14 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 continue;
             }
             if (CHECK) {
-                float fkl = 0.f, fd = 0.f, fx = 0.f;
+                float fkl = 0.f, fd = 0.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float x = xr[r], y = clamp_eps(r < 4 ? s0[r] : s1[r - 4]);
-                    if (x > 0.f) { fkl += x * (logf(x) - logf(y)) - x + y; fd += fabsf(x - y); fx += fabsf(x); }
+                    fkl = __builtin_fmaf(x, log2_hw(y), fkl); fd += fabsf(x - y);   // the X-only terms of cuda/matrix.cu:592,517-518 are summed once at upload
                 }
-                kl += (double)fkl; dabs += (double)fd; xabs += (double)fx;
+                kl += (double)fkl; dabs += (double)fd;
                 x_relayout();
-#pragma unroll
-                for (int w = 0; w < 4 * NST; ++w) stage_store_one(vn, w);
                 __syncthreads();
                 continue;
             }

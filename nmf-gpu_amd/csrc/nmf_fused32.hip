@@ -446,11 +446,10 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a, doub
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float x = xr[r], y = clamp_eps(s[r]);
-                    if (x > 0.f) {   // padding is exactly 0; real inputs are >= EPS (cuda/nmf.cu:211)
-                        fkl += x * (logf(x) - logf(y)) - x + y;   // cuda/matrix.cu:592
-                        fd += fabsf(x - y);                       // cuda/matrix.cu:517
-                        fx += fabsf(x);                           // cuda/matrix.cu:518
-                    }
+                    // sum x log y and sum |x - y|; the X-only terms of cuda/matrix.cu:592,517-518 are summed once at upload and
+                    // sum y comes from the normalisers (launch_check_compose).  Padding: x = 0, y = EPS, both terms vanish to 1e-16
+                    fkl = __builtin_fmaf(x, log2_hw(y), fkl);
+                    fd += fabsf(x - y);
                 }
                 kl += (double)fkl; dabs += (double)fd; xabs += (double)fx;
                 x_relayout();
@@ -634,11 +633,8 @@ __global__ __launch_bounds__(256, 1) void check_kernel(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float x = xr[r], y = clamp_eps(s[r]);
-            if (x > 0.f) {   // padding is exactly 0; real inputs are >= EPS (cuda/nmf.cu:211)
-                fkl += x * (logf(x) - logf(y)) - x + y;   // cuda/matrix.cu:592
-                fd += fabsf(x - y);                       // cuda/matrix.cu:517
-                fx += fabsf(x);                           // cuda/matrix.cu:518
-            }
+            fkl = __builtin_fmaf(x, log2_hw(y), fkl);   // see fused_step_kernel_v3<CHECK>
+            fd += fabsf(x - y);
         }
         kl += (double)fkl; dabs += (double)fd; xabs += (double)fx;
         if (more) load_x<false>(xr, X, Mp, (ch + 1) * 32, q0, c, h);

@@ -125,6 +125,7 @@ struct nmf_solver {
     float *psum = nullptr;         // Mp*Kp + Kp floats: [sum_g Z*H' ; rowsum(H)] (all-reduce operand)
     float *psum_owned = nullptr;   // the allocation behind psum unless the caller supplied one
     double *chk_part = nullptr, *chk_out = nullptr, *chk_host = nullptr;
+    double *xc_part = nullptr, *xc3 = nullptr, *sum64 = nullptr;   // the check's X-only terms and fp64 factor sums (launch_x_consts / launch_check_compose)
     int chk_groups = 0;
     float *Z = nullptr, *WtZ = nullptr, *ZHt = nullptr;   // unfused temporaries (cuda/nmf.cu:94-96)
     float *staging = nullptr;      // unpadded upload/download staging (max of the three matrices)
@@ -299,6 +300,13 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         HIPCHK(hipStreamSynchronize(s->stream));
     }
     HIPCHK(hipMalloc((void **)&s->range_flag, sizeof(unsigned)));
+    if (path == NMF_PATH_FUSED) {
+        HIPCHK(hipMalloc((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups));
+        HIPCHK(hipMalloc((void **)&s->xc3, sizeof(double) * 3));
+        HIPCHK(hipMalloc((void **)&s->sum64, sizeof(double) * (size_t)s->Kp * (1 + kSum64Blocks)));
+        if (x_from) HIPCHK(hipMemcpyAsync(s->xc3, x_from->xc3, sizeof(double) * 3, hipMemcpyDeviceToDevice, s->stream));
+        else HIPCHK(hipMemsetAsync(s->xc3, 0, sizeof(double) * 3, s->stream));
+    }
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
     if ((size_t)K * N > s->staging_count) s->staging_count = (size_t)K * N;
@@ -322,6 +330,9 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->chk_out) (void)hipFree(s->chk_out);
     if (s->chk_host) (void)hipHostFree(s->chk_host);
     if (s->range_flag) (void)hipFree(s->range_flag);
+    if (s->xc_part) (void)hipFree(s->xc_part);
+    if (s->xc3) (void)hipFree(s->xc3);
+    if (s->sum64) (void)hipFree(s->sum64);
     if (s->active_d) (void)hipFree(s->active_d);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -347,6 +358,7 @@ static int upload_one(nmf_solver *s, float *dst, int rows_p, int cols_p, const f
     if (dst == s->W) s->normW_fresh = false;
     if (is_x) HIPCHK(hipMemsetAsync(s->range_flag, 0, sizeof(unsigned), s->stream));
     HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, is_x ? s->range_flag : nullptr, s->stream));
+    if (is_x && s->xc3) HIPCHK(launch_x_consts(s->X, (size_t)s->Mp * s->Np, s->xc_part, s->xc3, s->stream));
     if (is_x) {
         unsigned flag = 1;
         HIPCHK(hipMemcpyAsync(&flag, s->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
@@ -783,14 +795,16 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
     {
         PieceScope p(s, NMF_T_CHECK);
         if (s->path == NMF_PATH_FUSED) {
-            HIPCHK(launch_check(s->W + (size_t)b * s->Mp * s->Kp, s->H + (size_t)b * s->Kp * s->Np, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+            const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
+            HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+            HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out, st));
         } else {
             const size_t mn = (size_t)s->Mp * s->Np;
             HIPCHK(launch_gemm(GEMM_NN, s->Mp, s->Np, s->Kp, s->W, s->Mp, s->H, s->Kp, s->Z, s->Mp, st));
             HIPCHK(launch_set_epsilon(s->Z, mn, st));
             HIPCHK(launch_kl_reduce(s->X, s->Z, mn, s->chk_part, st));
+            HIPCHK(launch_check_final(s->chk_part, s->chk_groups, s->chk_out, st));
         }
-        HIPCHK(launch_check_final(s->chk_part, s->chk_groups, s->chk_out, st));
         if (s->comm) NMFCHK(nmf_comm_allreduce_f64(s->comm, s->chk_out, 3, st));
     }
     HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
@@ -806,8 +820,9 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     if (s->path != NMF_PATH_FUSED) { set_err("check_all: fused path only"); return NMF_ERR_UNSUPPORTED; }
     hipStream_t st = s->stream;
     for (int b = 0; b < s->batch; ++b) {
-        HIPCHK(launch_check(s->W + (size_t)b * s->Mp * s->Kp, s->H + (size_t)b * s->Kp * s->Np, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
-        HIPCHK(launch_check_final(s->chk_part, s->chk_groups, s->chk_out + 3 * (size_t)b, st));
+        const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
+        HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+        HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
     }
     HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

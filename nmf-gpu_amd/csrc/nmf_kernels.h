@@ -95,8 +95,14 @@ hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, s
 // W[m,k] *= psum[m,k] / max(hsum[k], EPS)
 hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp, int Kp, hipStream_t stream);
 
-// KL(X || max(W*H,EPS)), sum|X-WH|, sum|X| over the valid (non-padded, X > 0) entries:
-// per-workgroup partial triples into `part` (3 doubles per workgroup), then launch_check_final.
+// The convergence check (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640) in one log per element:
+//     KL = sum x (log x - log y) - x + y  =  [sum x log x - x]  -  [sum x log y]  +  [sum y],      y = max(W*H, EPS)
+//   * sum x log x - x and sum |x| depend on X alone: launch_x_consts, once per upload, fp64;
+//   * sum x log y and sum |x - y| need W*H: launch_check (the half-step kernels in CHECK mode: product 1 only, W*H never
+//     materialised), per-workgroup partial triples {sum x log2 y, sum |x - y|, 0} in `part`;
+//   * sum y = sum_k colsum(W)_k rowsum(H)_k needs no pass over M x N: launch_check_compose sums the factors in fp64 (the
+//     three terms cancel to 1e-2..1e-3 of their size, so fp32 normalisers would cost digits), adds the partials in fixed
+//     order and leaves {KL, sum|X-WH|, sum|X|} in out3.
 int        check_num_groups(int Np, int Kp);
 bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
@@ -104,6 +110,13 @@ int        fused_pad_k(int K);             // K padded to an instantiated kernel
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,
                         double *part, hipStream_t stream);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
+constexpr int kXConstGroups = 1024;     // partial triples of launch_x_consts
+constexpr int kSum64Blocks = 128;       // column blocks of the fp64 row sums of H
+// xc3 <- {sum x log x - x, sum |x|, 0} over the n floats of X (zeros skipped); part: 3 * kXConstGroups doubles of scratch
+hipError_t launch_x_consts(const float *X, size_t n, double *part, double *xc3, hipStream_t stream);
+// scratch64: Kp + kSum64Blocks * Kp doubles
+hipError_t launch_check_compose(const double *part, int ngroups, const float *W, const float *H, int Mp, int Np, int Kp,
+                                const double *xc3, double *scratch64, double *out3, hipStream_t stream);
 
 // ---------------------------------------------------------------- normalisers
 // out[k] = max(sum_i A[i + k*ld], EPS), one workgroup per column (sum_cols + set_epsilon, cuda/nmf.cu:134-135)

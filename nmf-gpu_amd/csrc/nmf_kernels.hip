@@ -155,6 +155,85 @@ hipError_t launch_check_final(const double *part, int ngroups, double *out3, hip
     return hipGetLastError();
 }
 
+// ---- the X-only terms of the check, once per upload
+__global__ __launch_bounds__(256) void x_consts_kernel(const float *__restrict__ x, size_t n, double *__restrict__ part) {
+    double a = 0.0, b = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float xv = x[i];
+        if (xv > 0.f) { const double xd = (double)xv; a += xd * log(xd) - xd; b += xd; }   // padding is exactly 0; NaN fails the test like in the reference's loop
+        else if (xv != xv) { a += (double)xv; b += (double)xv; }
+    }
+    block_reduce3(a, b, 0.0, part + 3 * (size_t)blockIdx.x, threadIdx.x);
+}
+hipError_t launch_x_consts(const float *X, size_t n, double *part, double *xc3, hipStream_t stream) {
+    size_t g = (n + 256 * 16 - 1) / (256 * 16);
+    if (g > (size_t)kXConstGroups) g = kXConstGroups;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(x_consts_kernel, dim3((unsigned)g), dim3(256), 0, stream, X, n, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_check_final(part, (int)g, xc3, stream);
+}
+
+// ---- sum y = sum_k colsum(W)_k rowsum(H)_k in fp64, and the composition of the three terms
+__global__ __launch_bounds__(256) void colsum64_kernel(const float *__restrict__ W, int Mp, double *__restrict__ out) {
+    __shared__ double red[4];
+    const float *__restrict__ a = W + (size_t)blockIdx.x * Mp;
+    double s0 = 0.0, s1 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 256 < Mp; i += 512) { s0 += (double)a[i]; s1 += (double)a[i + 256]; }
+    if (i < Mp) s0 += (double)a[i];
+    double s = wave_sum(s0 + s1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// part[b][k] = sum over column block b of H[k, :]; threads run along k (coalesced), four columns in flight
+__global__ __launch_bounds__(256) void rowsum64_kernel(const float *__restrict__ H, int Kp, int Np, double *__restrict__ part) {
+    const int per = (Np + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = blockIdx.x * per, c1 = (c0 + per < Np) ? c0 + per : Np;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        const float *__restrict__ a = H + (size_t)k;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = c0;
+        for (; c + 4 <= c1; c += 4) {
+            s0 += (double)a[(size_t)c * Kp]; s1 += (double)a[(size_t)(c + 1) * Kp];
+            s2 += (double)a[(size_t)(c + 2) * Kp]; s3 += (double)a[(size_t)(c + 3) * Kp];
+        }
+        for (; c < c1; ++c) s0 += (double)a[(size_t)c * Kp];
+        part[(size_t)blockIdx.x * Kp + k] = (s0 + s1) + (s2 + s3);
+    }
+}
+__global__ __launch_bounds__(256) void check_compose_kernel(const double *__restrict__ part, int ngroups, const double *__restrict__ wsum,
+                                                            const double *__restrict__ hpart, int nblk, int Kp, const double *__restrict__ xc3,
+                                                            double *__restrict__ out3) {
+    double sy = 0.0, sxly = 0.0, sd = 0.0;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        double rh = 0.0;
+        for (int b = 0; b < nblk; ++b) rh += hpart[(size_t)b * Kp + k];
+        sy += wsum[k] * rh;
+    }
+    for (int g = threadIdx.x; g < ngroups; g += 256) { sxly += part[3 * (size_t)g]; sd += part[3 * (size_t)g + 1]; }
+    __shared__ double tot[3];
+    block_reduce3(sy, sxly, sd, tot, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out3[0] = xc3[0] - 0.69314718055994530942 * tot[1] + tot[0];   // [sum x log x - x] - ln 2 [sum x log2 y] + [sum y]
+        out3[1] = tot[2];
+        out3[2] = xc3[1];
+    }
+}
+hipError_t launch_check_compose(const double *part, int ngroups, const float *W, const float *H, int Mp, int Np, int Kp,
+                                const double *xc3, double *scratch64, double *out3, hipStream_t stream) {
+    double *wsum = scratch64, *hpart = scratch64 + Kp;
+    int nblk = (Np + 63) / 64;
+    if (nblk > kSum64Blocks) nblk = kSum64Blocks;
+    hipLaunchKernelGGL(colsum64_kernel, dim3(Kp), dim3(256), 0, stream, W, Mp, wsum);
+    hipLaunchKernelGGL(rowsum64_kernel, dim3(nblk), dim3(256), 0, stream, H, Kp, Np, hpart);
+    hipLaunchKernelGGL(check_compose_kernel, dim3(1), dim3(256), 0, stream, part, ngroups, wsum, hpart, nblk, Kp, xc3, out3);
+    return hipGetLastError();
+}
+
 // generic flat version for the unfused path: x = X, y = WH (already clamped by the caller)
 __global__ __launch_bounds__(256) void kl_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, size_t n, double *__restrict__ part) {
     double kl = 0.0, dabs = 0.0, xabs = 0.0;

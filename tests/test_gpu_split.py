@@ -249,3 +249,27 @@ def test_update_div_accepts_numpy_arrays_and_updates_them_in_place(ng, oracle):
     ro.setflags(write=False)
     with pytest.raises(TypeError):
         ng.update_div(ro, H, X, 0.0, 1, None, 0)
+
+
+@pytest.mark.parametrize("M,N,K,split_kernel", [(1024, 4096, 64, 0), (700, 1300, 256, 0), (300, 500, 30, -1), (2048, 8192, 128, -1)])
+def test_check_in_one_log_per_element_matches_an_fp64_evaluation(ng, oracle, M, N, K, split_kernel):
+    """KL = [sum x log x - x] - [sum x log y] + [sum y] with the first term summed once at upload, the last from fp64
+    column / row sums of the factors, and only sum x log y and sum |x - y| taken behind W*H (cuda/matrix.cu:592, 517-518):
+    against a float64 numpy evaluation of the textbook formula on the same factors, 2e-6 relative (the three terms are
+    ~100x the KL value at this point of the run, so this is ~1e-8 of each term), and 1e-6 against oracle.kl_div"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=31)
+    s = ng.Solver(M, N, K, split_kernel=split_kernel)
+    s.upload(W, H, X)
+    s.iterate(7)
+    kl, rl1 = s.check()
+    Wg, Hg = s.download()
+    s.close()
+    x = np.maximum(X, oracle.EPS).astype(np.float64)
+    y = np.maximum(Wg.astype(np.float64) @ Hg.astype(np.float64), float(oracle.EPS))
+    ref = float((x * (np.log(x) - np.log(y)) - x + y).sum())
+    ref_l1 = float(np.abs(x - y).sum() / np.abs(x).sum())
+    assert abs(kl - ref) <= 2e-6 * abs(ref), (kl, ref)
+    assert abs(rl1 - ref_l1) <= 1e-5 * ref_l1, (rl1, ref_l1)
+    y32 = np.maximum(oracle.sgemm("nn", Wg, Hg), oracle.EPS)
+    klo = oracle.kl_div(oracle.clamp(X), y32)
+    assert abs(kl - klo) <= 2e-6 * abs(klo), (kl, klo)

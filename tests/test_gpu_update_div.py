@@ -245,6 +245,18 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     s.close()
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 2, 25)
     print("cfg3 K_par=2 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
+    # K_par = 10 ("K_par iterations small enough for the CPU to finish", ~0.55 TFLOP each): the oracle's fast
+    # arrangement (same arithmetic around its fastest SGEMM kernel) first has to equal the pinned loop at THIS shape
+    W1r, H1r, _, _ = oracle.update_div(W, H, X, 0.0, 1, 25)
+    W1f, H1f = oracle.update_div_fast(W, H, X, 1)
+    assert oracle.relF(W1f, W1r) < 5e-6 and oracle.relF(H1f, H1r) < 5e-6
+    W10, H10 = oracle.update_div_fast(W, H, X, 10)
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(10)
+    Wg, Hg = s.download()
+    s.close()
+    print("cfg3 K_par=10 relF =", _cmp(oracle, Wg, Hg, W10, H10, 2e-5, wh=False))
 
 
 def test_cfg3_200_iterations_kl_monotone(ng):
@@ -279,8 +291,19 @@ def test_cfg5_tall_skinny_r512(ng, oracle):
     s.iterate(1)
     Wg, Hg = s.download()
     s.close()
-    Wr, Hr, _, _ = oracle.update_div(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]), 0.0, 1, 25)
+    Hs, Xs = np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns])
+    Wr, Hr, _, _ = oracle.update_div(W, Hs, Xs, 0.0, 1, 25)
     print("cfg5 shard K_par=1 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
+    # K_par = 5 through the oracle's fast arrangement, validated against the pinned loop at this shape first
+    W1f, H1f = oracle.update_div_fast(W, Hs, Xs, 1)
+    assert oracle.relF(W1f, Wr) < 5e-6 and oracle.relF(H1f, Hr) < 5e-6
+    W5, H5 = oracle.update_div_fast(W, Hs, Xs, 5)
+    s = ng.Solver(M, ns, K)
+    s.upload(W, Hs, Xs)
+    s.iterate(5)
+    Wg, Hg = s.download()
+    s.close()
+    print("cfg5 shard K_par=5 relF =", _cmp(oracle, Wg, Hg, W5, H5, 2e-5, wh=False))
     # 200 iterations on the shard shape: KL decreases at every check (SURVEY 8d gate for shapes the CPU cannot iterate)
     s = ng.Solver(M, ns, K)
     s.upload(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]))

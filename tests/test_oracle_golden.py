@@ -52,13 +52,44 @@ def test_refcompat_reproduces_reference_golden_outputs(oracle):
     assert it == 200 and Wg.shape == (4096, 128) and Hg.shape == (128, 350)
     eW, eH = oracle.relF(w, Wg), oracle.relF(h, Hg)
     print("refcompat vs gold: relF(W)=%.3g relF(H)=%.3g" % (eW, eH))
-    assert eW < 2e-4 and eH < 1.5e-3
+    assert eW < 1e-4 and eH < 6e-4       # measured 6.8e-5 / 4.3e-4; why not smaller: test_gold_distance_is_summation_order_noise
     assert abs(int((w == 0).sum()) - 457204) <= 5 and int((h == 0).sum()) == 38850
     surv = np.flatnonzero(h.sum(axis=1) > 0)
     assert list(surv) == [1, 22, 30, 34, 43, 45, 57, 70, 88, 89, 93, 96, 110, 113, 118, 121, 126]
     assert list(np.flatnonzero(Hg.sum(axis=1) > 0)) == list(surv)
     # sum(W) is conserved = sum(X) when row_divide never runs
     assert abs(float(w.sum(dtype=np.float64)) - float(np.maximum(X, oracle.EPS).sum(dtype=np.float64))) < 1.0
+
+
+def test_gold_distance_is_summation_order_noise(oracle):
+    """The reference's four GEMMs ran in closed-source cuBLAS (cuda/matrix.cu:101-124), whose summation order over k is
+    unknowable, so bit parity with Wtest/Htest is impossible by construction.  This test turns the tolerance above from an
+    allowance into a measurement: the SAME model (refcompat) is run with the K components relabelled -- columns of W and
+    rows of H permuted, results un-permuted -- which changes nothing mathematically, only the order in which fp32 sums over
+    k are taken.  After 200 iterations of the winner-take-all dynamic two such runs differ from each other by 2.5e-5..4.9e-5
+    (W) and 8e-5..1.8e-4 (H), and each is 6.8e-5..9.9e-5 (W) / 2.7e-4..4.3e-4 (H) from the gold (measured here, 8 threads).
+    Asserted: (i) order alone moves the result by more than 1e-5; (ii) the gold lies within 4x the largest distance between
+    two order-perturbed runs of our own model, i.e. it is one more member of that cloud, not a different model; (iii) the
+    discrete outcome (which entries of H are exactly zero, which 17 components survive) is identical in every run."""
+    X, W, H = oracle.gen_problem(4096, 350, 128, seed=0)
+    Wg = oracle.read_bin(os.path.join(GOLDEN, "Wtest.bin"))
+    Hg = oracle.read_bin(os.path.join(GOLDEN, "Htest.bin"))
+    perms = [np.arange(128), np.arange(128)[::-1].copy(), np.random.default_rng(1).permutation(128)]
+    runs = []
+    for p in perms:
+        w, h, it, _ = oracle.update_div(np.asfortranarray(W[:, p]), np.asfortranarray(H[p, :]), X, 0.0, 200, 25, oracle.MODE_REFCOMPAT)
+        inv = np.argsort(p)
+        runs.append((np.asfortranarray(w[:, inv]), np.asfortranarray(h[inv, :])))
+    gold = [(oracle.relF(w, Wg), oracle.relF(h, Hg)) for w, h in runs]
+    pair = [(oracle.relF(runs[i][0], runs[j][0]), oracle.relF(runs[i][1], runs[j][1])) for i in range(3) for j in range(i + 1, 3)]
+    print("to gold:", gold, "pairwise:", pair)
+    sW, sH = max(p[0] for p in pair), max(p[1] for p in pair)
+    assert min(p[0] for p in pair) > 1e-5 and min(p[1] for p in pair) > 1e-5
+    for eW, eH in gold:
+        assert eW < 4 * sW and eH < 4 * sH and eW < 1.5e-4 and eH < 6e-4
+    for w, h in runs:
+        assert np.array_equal(h == 0, Hg == 0)
+        assert list(np.flatnonzero(h.sum(axis=1) > 0)) == [1, 22, 30, 34, 43, 45, 57, 70, 88, 89, 93, 96, 110, 113, 118, 121, 126]
 
 
 def test_spec_mode_is_not_the_golden_model(oracle):
