@@ -7,8 +7,13 @@ iteration) against the fp32 MFMA roofline, with the CPU oracle timed 
 
 N = 1: BASELINE config 3, (M, N, K) = (4096, 65536, 256), fp32, W/H/X resident in HBM.
 N > 1: weak scaling -- every rank owns 65536 columns of X and H (N = 4 is BASELINE config 4,
-       M=4096 N=262144 R=256), W replicated, one all-reduce of [Z*H' ; rowsum(H)] per iteration.
+       M=4096 N=262144 R=256), W replicated, one all-reduce of [Z*H' ; rowsum(H)] per iteration
+       (in-library RCCL captured inside each rank's hipGraph; --comm torch: torch.distributed, eager).
 A "step" is one full iteration (H half-step + W half-step, cuda/nmf.cu:108-109).
+Protocol: W warm-up steps, then `--repeats` (5) timed regions of exactly K steps each, every region
+bracketed by barrier + synchronize and maxed over ranks; `value` / `ms_per_step` are the MEDIAN region, all regions are
+listed in `repeats_ms_per_step`.  Inputs: X -> W -> H from one MT19937 stream, seed 0 (rank r > 0: X_r, H_r from seed r,
+W from seed 0's stream position), column-major, as matrix_export.py:4-7 extended to other shapes.
 """
 import argparse
 import json
@@ -22,22 +27,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz
-# HBM bytes per fused_step launch at cfg3 from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
-# profiles/r01_pmc_summary.md).  bench.py cannot collect PMC itself; other shapes report null.
-PMC_TRAFFIC_BYTES = {(4096, 65536, 256): {"H": 1.368e9, "W": 1.209e9}}
-# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of the same launches, same PMC runs
-PMC_MFMA_BUSY = {(4096, 65536, 256): {"H": 0.912, "W": 0.917}}
+# PMC numbers are NOT measured by this script (counters need rocprofv3 passes of their own): the block below is copied from
+# the committed profile of this command and is reported under "pmc_static" with its source, never mixed into live values.
+PMC_STATIC = {(4096, 65536, 256): {
+    "source": "profiles/r02_pmc_summary.md: rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (not this run)",
+    "hbm_bytes_per_launch": {"H": 1.368e9, "W": 1.209e9}, "algorithmic_bytes_per_launch": 1.21e9,
+    "mfma_busy_frac_of_simd_cycles": {"H": 0.912, "W": 0.917}}}
 
 
-def synth(seed, rows, cols):
-    """U[0,1) fp32 from numpy's legacy MT19937 (the generator matrix_export.py:4-7 uses),
-    column-major; chunked so the fp64 temporaries stay small."""
-    rs = np.random.RandomState(seed)
-    out = np.empty(rows * cols, dtype=np.float32)
+def _draw(rs, rows, cols, keep=True):
+    """rows*cols values of U[0,1) fp32 from the legacy MT19937 stream `rs` (what matrix_export.py:4-7 uses), the flat
+    buffer read column-major; chunked so the fp64 temporaries stay small.  keep=False only advances the stream."""
+    n = rows * cols
+    out = np.empty(n, dtype=np.float32) if keep else None
     step = 1 << 24
-    for i in range(0, out.size, step):
-        out[i:i + step] = rs.rand(min(step, out.size - i))
-    return out.reshape((rows, cols), order="F")
+    for i in range(0, n, step):
+        v = rs.rand(min(step, n - i))
+        if keep:
+            out[i:i + step] = v
+    return out.reshape((rows, cols), order="F") if keep else None
+
+
+def synth_problem(rank, M, Nloc, K):
+    """X -> W -> H from ONE stream.  Rank 0 / single GPU: seed 0, exactly matrix_export.py's recipe at this shape.
+    Rank r > 0 draws its own column block X_r, H_r from seed r and takes the replicated W from seed 0's stream position."""
+    rs = np.random.RandomState(rank)
+    X = _draw(rs, M, Nloc)
+    W = _draw(rs, M, K)
+    H = _draw(rs, K, Nloc)
+    if rank != 0:
+        r0 = np.random.RandomState(0)
+        _draw(r0, M, Nloc, keep=False)
+        W = _draw(r0, M, K)
+    return X, W, H
 
 
 def cpu_baseline(M, Nfull, K, budget_s=20.0):
@@ -46,7 +68,7 @@ def cpu_baseline(M, Nfull, K, budget_s=20.0):
     arithmetic arranged around its fastest SGEMM kernel, oracle/nmf_oracle_fast.c)."""
     import oracle
     Ns = min(Nfull, 8192)
-    X = synth(1000, M, Ns); W = synth(0, M, K); H = synth(2000, K, Ns)
+    X, W, H = synth_problem(0, M, Ns, K)
     try:
         oracle.lib(native=True)
         native = True
@@ -63,7 +85,9 @@ def cpu_baseline(M, Nfull, K, budget_s=20.0):
     flops = 8.0 * M * Ns * K * iters
     tf = flops / t / 1e12
     return {"value": tf, "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"oracle spec-mode update_div (oracle_fast_update_div), M={M} K={K}, first {Ns} of {Nfull} columns, {iters} iterations in {t:.1f} s"
+            "sample": f"oracle spec-mode update_div through oracle_fast_update_div (the oracle's arithmetic arranged around its fastest SGEMM kernel; "
+                      f"equal to the golden-pinned loop to 5e-6 relF, tests/test_oracle_ops.py, not the pinned routine itself), M={M} K={K}, {Ns} of {Nfull} columns "
+                      f"(same generator, seed 0), {iters} iterations in {t:.1f} s"
                       f" ({'-march=native' if native else 'avx2'} build); = {tf * 1e12 / (8.0 * M * Nfull * K):.4f} full-size iterations/s",
             "iterations_per_s_full_size": tf * 1e12 / (8.0 * M * Nfull * K)}
 
@@ -76,8 +100,10 @@ def main():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=65536, help="columns PER GPU")
     ap.add_argument("--K", type=int, default=256)
-    ap.add_argument("--comm", choices=["torch", "rccl"], default="torch",
-                    help="N>1: all-reduce through torch.distributed (default) or in-library RCCL inside the hipGraph")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
+                    help="N>1: all-reduce by in-library RCCL captured inside the per-iteration hipGraph (rccl; auto = rccl, falling "
+                         "back to torch if the communicator cannot be set up) or through torch.distributed, eager (torch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline sample")
     ap.add_argument("--strong-total-N", type=int, default=0,
@@ -128,20 +154,35 @@ def main():
     flops_per_iter = 8.0 * M * Ntot * K
 
     # synthetic inputs (data: "synthetic"), already resident in HBM before the timed region
-    W = synth(0, M, K)
-    X = synth(1000 + rank, M, Nloc)
-    H = synth(2000 + rank, K, Nloc)
+    X, W, H = synth_problem(rank, M, Nloc, K)
 
     comm = None
     shard = None
-    if sharded and args.comm == "rccl":
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(ng.Comm.unique_id()), dtype=torch.uint8).clone()
-        uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-    if sharded and args.comm == "torch":
+    comm_used = args.comm
+    if sharded and args.comm in ("auto", "rccl"):
+        ok = 1
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(ng.Comm.unique_id()), dtype=torch.uint8).clone()
+            uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as e:      # no librccl, init failure, ...
+            ok = 0
+            if args.comm == "rccl":
+                raise
+            print(f"bench.py rank {rank}: in-library RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            comm_used = "torch"
+        else:
+            comm_used = "rccl"
+    if sharded and comm_used == "torch":
         # half-step protocol + torch.distributed all-reduce of the (M*K + K)-float partial buffer
         shard = ng.GpuShard(M, Nloc, K, device=local_rank)
         s = shard.solver
@@ -167,14 +208,18 @@ def main():
     kl0, _ = s.check()
     step(args.warmup)
     fence()
-    t0 = time.perf_counter()
-    step(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    region = []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        step(args.steps)
+        fence()
+        dt_r = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt_r], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_r = float(tt.item())
+        region.append(dt_r)
+    dt = float(np.median(region))
     kl1, _ = s.check()
     if dist is not None and comm is None:
         kk = torch.tensor([kl0, kl1], dtype=torch.float64, device="cuda")
@@ -207,10 +252,12 @@ def main():
             "iterations_per_s": its,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "timed_repeats": len(region), "repeats_ms_per_step": [r / args.steps * 1e3 for r in region],
+            "ms_per_step_min": min(region) / args.steps * 1e3, "ms_per_step_max": max(region) / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.strong_total_N else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
-                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {args.comm})" if sharded else " (BASELINE config 3)"),
+                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {comm_used})" if sharded else " (BASELINE config 3)"),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
                        "hipgraph": (not args.no_graph) and shard is None,
                        "parallelism": f"N-sharded x{world}" if sharded else "single GPU"},
@@ -218,12 +265,9 @@ def main():
             "kl_before": kl0, "kl_after": kl1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_summary.md); algorithmic 1.21e9",
-                         "hbm_gbps": (PMC_TRAFFIC_BYTES[(M, Nloc, K)]["H" if ms_h >= ms_w else "W"] / (ms_k * 1e-3) / 1e9) if (M, Nloc, K) in PMC_TRAFFIC_BYTES else None,
-                         "hbm_peak_gbps": 8000.0,
-                         "mfma_busy_pmc": PMC_MFMA_BUSY.get((M, Nloc, K), {}).get("H" if ms_h >= ms_w else "W"),
-                         "kernel": "%s (%s-step instantiation, the slower of the two)" % ("fused_step_kernel_v3<KT=1>" if K <= 32 else "fused_step_kernel_k16<NB=%d>" % (-(-K // 64)), "H" if ms_h >= ms_w else "W"),
+                         "traffic": None,     # HBM bytes are a PMC quantity: not collected by this run, see pmc_static
+                         "pmc_static": PMC_STATIC.get((M, Nloc, K)),
+                         "kernel": "%s (%s-step launch, the slower of the two)" % (s.describe(), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
                          "measured": how},

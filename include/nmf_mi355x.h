@@ -208,7 +208,9 @@ int  nmf_solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, i
 int  nmf_solver_sync(nmf_solver *s);
 /* time one piece in isolation: which = NMF_T_H_STEP / NMF_T_W_STEP / NMF_T_SUMS / NMF_T_APPLY /
  * NMF_T_CHECK; runs it `reps` times between two hipEvents on the solver's stream and returns the
- * average milliseconds per launch of the dominant kernel of that piece. */
+ * average milliseconds per launch of the dominant kernel of that piece.  Any other `which` is NMF_ERR_ARG in the
+ * shipped library; a diagnostic build (make DIAG=1 in nmf-gpu_amd/csrc) adds the measurement probes of tools/probe.py
+ * and tools/divide_exhaustive.py there. */
 int  nmf_solver_time_piece(nmf_solver *s, int which, int reps, double *ms_per_launch);
 /* sharded runs where the caller performs the all-reduce itself (e.g. torch.distributed):
  * w_partial leaves sum_g-local [Z*H' (M*K floats) ; rowsum(H) (K floats)] in a device buffer
@@ -235,6 +237,8 @@ int  nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1);
 /* 1 if this solver runs the split kernel (see nmf_opts.split_kernel) */
 int  nmf_solver_uses_split_kernel(const nmf_solver *s);
 int  nmf_solver_path(const nmf_solver *s);
+/* one line: kernel family, padded shape, split counts (for logs and bench records) */
+int  nmf_solver_describe(const nmf_solver *s, char *buf, int buflen);
 void *nmf_solver_stream(nmf_solver *s);
 
 /* ---------------------------------------------------------------------------------------

@@ -114,6 +114,7 @@ _SIGS = [
     ("nmf_solver_check_all", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("nmf_solver_uses_split_kernel", C.c_int, [C.c_void_p]),
     ("nmf_solver_path", C.c_int, [C.c_void_p]),
+    ("nmf_solver_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("nmf_solver_stream", C.c_void_p, [C.c_void_p]),
     ("nmf_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("nmf_comm_init_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
@@ -452,6 +453,11 @@ class Solver:
         H = np.empty((self.K, self.N), dtype=np.float32, order="F")
         _chk(lib().nmf_solver_download(self._h, W.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
         return W, H
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(256)
+        _chk(lib().nmf_solver_describe(self._h, buf, 256))
+        return buf.value.decode()
 
     @property
     def uses_split_kernel(self) -> bool:

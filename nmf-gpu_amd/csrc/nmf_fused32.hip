@@ -560,6 +560,7 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
     return hipGetLastError();
 }
 
+#ifdef NMF_DIAGNOSTICS   // make DIAG=1: stamp and ablation instantiations, reached through nmf_solver_time_piece(which >= 100)
 // diagnostic: v3 H-step (KT = 8, in place, IEEE divide) with in-kernel stamps; a.partials receives 5 x uint64 per wave
 hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream) {
     if (a.Kp != 256 || !a.partials) return hipErrorInvalidValue;
@@ -589,6 +590,8 @@ hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream) {
 #undef NMF_PROBE
     return hipGetLastError();
 }
+
+#endif   // NMF_DIAGNOSTICS
 
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream) {
     switch (a.Kp / 32) {

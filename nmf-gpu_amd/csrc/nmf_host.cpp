@@ -339,6 +339,15 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
 }
 
 extern "C" int nmf_solver_path(const nmf_solver *s) { return s ? s->path : 0; }
+// one line for logs and bench records: which kernel family runs, on which padded shape, with which split counts
+extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
+    if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
+    if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
+    else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kp / 64, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
+    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 64, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    return NMF_OK;
+}
 extern "C" void *nmf_solver_stream(nmf_solver *s) { return s ? (void *)s->stream : nullptr; }
 extern "C" int nmf_solver_sync(nmf_solver *s) {
     if (!s) return NMF_ERR_ARG;
@@ -902,6 +911,10 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
     FusedArgs fa = fused_args(s);
     const size_t mk = (size_t)s->Mp * s->Kp;
     s->normW_fresh = false;   // the timed pieces overwrite W and H outside the iteration protocol
+#ifdef NMF_DIAGNOSTICS
+    static void *diag_scratch = nullptr;   // 128 bytes of their own for the divide census / exhaustive probes
+    if (which >= 4000 && !diag_scratch) HIPCHK(hipMalloc(&diag_scratch, 128));
+#endif
     // normalisers must be valid before timing an in-place fused step
     HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st));
     HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st));
@@ -932,23 +945,24 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
                 break;
             default:
+#ifdef NMF_DIAGNOSTICS   // make DIAG=1; the shipped library answers NMF_ERR_ARG
                 if (which >= 4001 && which <= 4004) {   // 4003: the 4-instruction variant   // 4001: slice i (of 64) of the exhaustive significand-pair comparison; 4002: rcp exponent invariance
-                    if (i == 0) HIPCHK(hipMemsetAsync(s->chk_part, 0, 88, st));
-                    HIPCHK(launch_divide_exhaustive((unsigned long long *)s->chk_part, which == 4002 ? -1 : (which == 4003 ? 64 + i : (which == 4004 ? 128 + i : i)), st));
+                    if (i == 0) HIPCHK(hipMemsetAsync(diag_scratch, 0, 88, st));
+                    HIPCHK(launch_divide_exhaustive((unsigned long long *)diag_scratch, which == 4002 ? -1 : (which == 4003 ? 64 + i : (which == 4004 ? 128 + i : i)), st));
                     HIPCHK(hipStreamSynchronize(st));
                     unsigned long long c[11];
-                    HIPCHK(hipMemcpy(c, s->chk_part, 88, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(c, diag_scratch, 88, hipMemcpyDeviceToHost));
                     if (which == 4002) { fprintf(stderr, "rcp exponent invariance: %llu of %llu (significand, exponent) cases differ\n", c[0], (1ull << 23) * 123); break; }
                     fprintf(stderr, "divide exhaustive: slice %d/%d done, %llu mismatches in %llu pairs so far\n", i + 1, reps, c[0], c[1]);
                     if (i + 1 == reps) for (unsigned long long k = 0; k < c[2] && k < 8; ++k) fprintf(stderr, "    e.g. mismatch at mx=0x%06llx my=0x%06llx\n", c[3 + k] >> 32, c[3 + k] & 0xFFFFFFFFull);
                     break;
                 }
                 if (which == 4000) {   // IEEE vs refined-reciprocal quotient: mismatch census over ~1e9 operand pairs
-                    HIPCHK(hipMemsetAsync(s->chk_part, 0, 16, st));
-                    HIPCHK(launch_divide_compare((unsigned long long *)s->chk_part, 12345u + (unsigned)i, st));
+                    HIPCHK(hipMemsetAsync(diag_scratch, 0, 16, st));
+                    HIPCHK(launch_divide_compare((unsigned long long *)diag_scratch, 12345u + (unsigned)i, st));
                     HIPCHK(hipStreamSynchronize(st));
                     unsigned long long c2[2];
-                    HIPCHK(hipMemcpy(c2, s->chk_part, 16, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(c2, diag_scratch, 16, hipMemcpyDeviceToHost));
                     fprintf(stderr, "divide census: %llu of %llu pairs differ, max distance %llu ulp\n", c2[0], 4096ull * 256 * 1000, c2[1]);
                     break;
                 }
@@ -979,6 +993,7 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                     HIPCHK(launch_fused_probe(fa, which - 100, st));
                     break;
                 }
+#endif
                 return NMF_ERR_ARG;
         }
     }

@@ -45,12 +45,14 @@ bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc)
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
+#ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe
 hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream);   // micro-probe 2
 hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream);   // diagnostic stamps
 hipError_t launch_divide_compare(unsigned long long *counts, unsigned seed, hipStream_t stream);   // diagnostic
 hipError_t launch_divide_exhaustive(unsigned long long *counts, int slice, hipStream_t stream);     // diagnostic (slice -1: rcp invariance)
 hipError_t launch_fused_probe(const FusedArgs &a, int abl, hipStream_t stream);   // timing probes (v1 kernel + ablation mask)
+#endif
 // ---------------------------------------------------------------- split half-steps (nmf_split16.hip)
 // The half-step for problems whose owned dimension is too short to fill the chip with one workgroup per 64 columns: the
 // four waves of a workgroup own the SAME 16 columns and split the reduction dimension (summed through LDS in fixed

@@ -1,5 +1,8 @@
 // nmf_probes.hip -- diagnostics only (never on the product path): the micro-probes behind profiles/r01_pmc_summary.md
 // and the division census / exhaustive comparison behind DESIGN.md 4.1c.  Reached through nmf_solver_time_piece(which >= 1000).
+#ifndef NMF_DIAGNOSTICS
+#define NMF_DIAGNOSTICS 1
+#endif
 #include "nmf_device.h"
 
 namespace nmf {
