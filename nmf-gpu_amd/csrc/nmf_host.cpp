@@ -7,6 +7,8 @@
 #include "nmf_comm.h"
 #include "nmf_kernels.h"
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -455,10 +457,38 @@ extern "C" int nmf_solver_set_active(nmf_solver *s, const int *flags) {
     return NMF_OK;
 }
 
+// --------------------------------------------------------------------- tracing: roctx ranges
+// One range per piece of an iteration (H-step, W-step, sums, apply, check, all-reduce) around its enqueue, so that
+// `rocprofv3 --marker-trace --kernel-trace` attributes kernels to pieces.  The roctx library is dlopen()ed, and only when the
+// process runs under a rocprofiler tool (LD_PRELOAD) or NMF_ROCTX=1 asks for it; NMF_ROCTX=0 switches it off.  Ranges bracket
+// host-side enqueues: a replayed hipGraph has none per piece, so trace with eager launches (`nmf --timers`, use_graph = 0).
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("NMF_ROCTX"), *pre = getenv("LD_PRELOAD");
+        const bool want = e ? (e[0] == '1') : (pre && strstr(pre, "rocprofiler") != nullptr);
+        if (!want) return;
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+const char *const kPieceName[10] = {"nmf:total", "nmf:h2d", "nmf:h_step", "nmf:w_step", "nmf:sums", "nmf:apply", "nmf:check", "nmf:allreduce", "nmf:d2h", "nmf:setup"};
+}  // namespace
+
 // --------------------------------------------------------------------- piece timing
 struct PieceScope {
-    nmf_solver *s; int idx = -1;
+    nmf_solver *s; int idx = -1; bool marked = false;
     PieceScope(nmf_solver *s_, int which) : s(s_) {
+        if (roctx().push && which >= 0 && which < 10) { roctx().push(kPieceName[which]); marked = true; }
         if (!s->timing) return;
         nmf_solver::Ev e; e.which = which;
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -466,7 +496,10 @@ struct PieceScope {
         s->events.push_back(e);
         idx = (int)s->events.size() - 1;
     }
-    ~PieceScope() { if (idx >= 0) (void)hipEventRecord(s->events[idx].b, s->stream); }
+    ~PieceScope() {
+        if (idx >= 0) (void)hipEventRecord(s->events[idx].b, s->stream);
+        if (marked) roctx().pop();
+    }
 };
 
 static int collect_timing(nmf_solver *s, double t[10]) {
