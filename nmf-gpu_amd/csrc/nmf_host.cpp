@@ -220,7 +220,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     if (batch > 1 && !s->split) { set_err("batched solvers need the split kernel (K <= 128)"); return NMF_ERR_UNSUPPORTED; }
     if (s->split) path = NMF_PATH_FUSED;
     // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
-    const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << 31);
+    const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
     if (path == NMF_PATH_AUTO) path = (fused_pad_k(K) && !k16_too_tall) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
@@ -346,6 +346,7 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kp / 64, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
+    else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 64, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     return NMF_OK;

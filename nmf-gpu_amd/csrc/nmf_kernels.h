@@ -10,7 +10,7 @@ namespace nmf {
 
 constexpr float kEps = (float)(2.2204E-16);   // cuda/matrix.cu:10
 constexpr int kPad = 32;                      // device buffers are padded to multiples of 32 (cf. PAD_MULT, cuda/matrix.cuh:7)
-constexpr int kMaxFusedK = 512;                // fused path: K <= 512 (32x32x2 kernel up to 256, 16x16x4 kernel above)
+constexpr int kMaxFusedK = 1024;               // fused path: K <= 1024 (32x32x2 kernel: K <= 32; 16x16x4 kernel: K <= 512; wave pairs above)
 
 inline int pad32(int v) { return (v + 31) & ~31; }
 
@@ -40,6 +40,9 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
 // the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 64 <= Kp <= 512; nmf_fused32.hip: Kp <= 256)
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
+// 512 < Kp <= 1024 (a multiple of 128): two waves share 16 owned columns and split K (nmf_pair16.hip)
+hipError_t launch_fused_pair(const FusedArgs &a, bool wstep, hipStream_t stream);
+hipError_t launch_check_pair(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
 // C = A * B through product 1 of the 16-column kernel (the W*H shape: tall A, K <= 512), see nmf_fused16.hip
 bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);

@@ -9,27 +9,32 @@ namespace nmf {
 
 // which kernel family serves a padded K: the 16-column kernel for K = 64/128/256 (two workgroups per CU) and for
 // 256 < K <= 512 (one), the 32-column v3 for K = 32 or when NMF_FUSED_VARIANT asks for it
-static bool use_k16(int Kp) { return Kp > 256 || (Kp >= 64 && fused_variant() == 0); }
+static bool use_pair(int Kp) { return Kp > 512; }   // two waves per 16 owned columns, K split between them (nmf_pair16.hip)
+static bool use_k16(int Kp) { return !use_pair(Kp) && (Kp > 256 || (Kp >= 64 && fused_variant() == 0)); }
 
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
     if ((a.Mp | a.Np | a.Kp) & 31) return hipErrorInvalidValue;
     if (a.nsplit < 1 || (a.nsplit > 1 && !a.partial)) return hipErrorInvalidValue;
+    if (use_pair(a.Kp)) return launch_fused_pair(a, wstep, stream);
     return use_k16(a.Kp) ? launch_fused16(a, wstep, stream) : launch_fused32(a, wstep, stream);
 }
 
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
     if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
+    if (use_pair(Kp)) return launch_check_pair(W, H, X, Mp, Np, Kp, part, stream);
     return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, part, stream) : launch_check32(W, H, X, Mp, Np, Kp, part, stream);
 }
 
 // one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows
 bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 4 >= (size_t)Kp; }
-int fused_cols_per_group(int Kp) { return use_k16(Kp) ? 64 : 128; }
+int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
 int fused_pad_k(int K) {   // padded K the fused kernels are instantiated for; 0 = not supported
     const int k32 = pad32(K);
     if (k32 <= 256) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
     const int k64 = (K + 63) & ~63;
-    return k64 <= 512 ? k64 : 0;
+    if (k64 <= 512) return k64;
+    const int k128 = (K + 127) & ~127;        // the pair kernel splits K in two halves of whole 64-blocks
+    return k128 <= kMaxFusedK ? k128 : 0;
 }
 int check_num_groups(int Np, int Kp) { return (Np + fused_cols_per_group(Kp) - 1) / fused_cols_per_group(Kp); }
 
@@ -209,9 +214,14 @@ __global__ __launch_bounds__(256) void check_compose_kernel(const double *__rest
                                                             double *__restrict__ out3) {
     double sy = 0.0, sxly = 0.0, sd = 0.0;
     for (int k = threadIdx.x; k < Kp; k += 256) {
-        double rh = 0.0;
-        for (int b = 0; b < nblk; ++b) rh += hpart[(size_t)b * Kp + k];
-        sy += wsum[k] * rh;
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;   // four loads in flight: one workgroup has nothing else to hide their latency
+        int b = 0;
+        for (; b + 4 <= nblk; b += 4) {
+            r0 += hpart[(size_t)b * Kp + k]; r1 += hpart[(size_t)(b + 1) * Kp + k];
+            r2 += hpart[(size_t)(b + 2) * Kp + k]; r3 += hpart[(size_t)(b + 3) * Kp + k];
+        }
+        for (; b < nblk; ++b) r0 += hpart[(size_t)b * Kp + k];
+        sy += wsum[k] * ((r0 + r1) + (r2 + r3));
     }
     for (int g = threadIdx.x; g < ngroups; g += 256) { sxly += part[3 * (size_t)g]; sd += part[3 * (size_t)g + 1]; }
     __shared__ double tot[3];

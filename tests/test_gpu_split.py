@@ -273,3 +273,68 @@ def test_check_in_one_log_per_element_matches_an_fp64_evaluation(ng, oracle, M, 
     y32 = np.maximum(oracle.sgemm("nn", Wg, Hg), oracle.EPS)
     klo = oracle.kl_div(oracle.clamp(X), y32)
     assert abs(kl - klo) <= 2e-6 * abs(klo), (kl, klo)
+
+
+# ------------------------------------------------------------------------------------------------ 512 < K <= 1024
+@pytest.mark.parametrize("M,N,K", [(256, 384, 640), (200, 130, 1000), (96, 520, 768), (320, 64, 900), (33, 70, 513), (700, 300, 1024)])
+def test_wave_pair_kernel_half_steps(ng, oracle, M, N, K):
+    """nmf_pair16.hip: two waves share 16 owned columns and split K.  One update_h, one update_w (cuda/nmf.cu:118-176) on
+    ragged sizes for every instantiation (K padded to 640 / 768 / 896 / 1024), against the oracle and the operator path"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=7)
+    s = ng.Solver(M, N, K, use_graph=False)
+    assert s.path == ng.PATH_FUSED and "pair" in s.describe()
+    s.upload(W, H, X)
+    s.update_h()
+    W1, H1 = s.download()
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert _relF(oracle, H1, Hr) < 5e-6 and np.array_equal(W1, oracle.clamp(W))
+    s.update_w()
+    W2, H2 = s.download()
+    Wr = oracle.update_w(oracle.clamp(W), Hr, oracle.clamp(X))
+    assert _relF(oracle, W2, Wr) < 5e-6 and np.array_equal(H2, H1)
+    s.close()
+
+
+@pytest.mark.parametrize("M,N,K,nh,nw", [(512, 2048, 1024, 0, 0), (1024, 700, 640, 2, 3), (300, 1500, 896, 1, 1)])
+def test_wave_pair_kernel_loop_check_graph_and_splits(ng, oracle, M, N, K, nh, nw):
+    """20 iterations with the KL check (the pair kernel in CHECK mode), hipGraph replay equal to eager launches bit for bit,
+    workgroup-level splits of the reduction dimension, all against the oracle; KL against an fp64 evaluation"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=9)
+    Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 20, 10)
+    outs = []
+    for graph in (True, False):
+        s = ng.Solver(M, N, K, use_graph=graph, nsplit_h=nh, nsplit_w=nw)
+        s.upload(W, H, X)
+        r = s.run(1e-30, 20, 10)
+        outs.append(s.download() + (r["kl"],))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    Wg, Hg, kl = outs[0]
+    assert _relF(oracle, Wg, Wr) < 1e-5 and _relF(oracle, Hg, Hr) < 1e-5
+    assert np.allclose(kl, klr, rtol=2e-5) and all(kl[i + 1] < kl[i] for i in range(len(kl) - 1))
+    x = np.maximum(X, oracle.EPS).astype(np.float64)
+    y = np.maximum(Wg.astype(np.float64) @ Hg.astype(np.float64), float(oracle.EPS))
+    ref = float((x * (np.log(x) - np.log(y)) - x + y).sum())
+    assert abs(kl[-1] - ref) <= 2e-6 * abs(ref)
+
+
+def test_wave_pair_kernel_nan_and_out_of_range_inputs(ng, oracle):
+    """the range-guarded quotient of the pair kernel must take the full IEEE sequence when X leaves [EPS, 2^60], and a NaN
+    must spread exactly as the reference's arithmetic spreads it (cuda/matrix.cu:185-186)"""
+    M, N, K = 128, 200, 640
+    X, W, H = oracle.gen_problem(M, N, K, seed=10)
+    X = X.copy(order="F")
+    X[0, 0], X[1, 0], X[3, 1] = 3e30, 1e-40, 1e25
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(3)
+    Wg, Hg = s.download()
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 3, 25)
+    assert np.isfinite(Wg).all() and _relF(oracle, Wg, Wr) < 1e-5 and _relF(oracle, Hg, Hr) < 1e-5
+    X[5, 7] = np.nan
+    s.upload(W, H, X)
+    s.update_h()
+    _, H1 = s.download()
+    s.close()
+    Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
+    assert np.array_equal(np.isnan(H1), np.isnan(Hr)) and np.isnan(H1).sum() == K

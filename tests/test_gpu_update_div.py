@@ -451,8 +451,8 @@ def test_k_between_256_and_512_fused_16x16x4_kernel(ng, oracle, M, N, K):
 
 
 def test_k_above_fused_limit_takes_unfused_path(ng, oracle):
-    """R > 512: PATH_AUTO must fall back to the operator path and stay in parity."""
-    M, N, K = 128, 192, 600
+    """R > 1024: PATH_AUTO must fall back to the operator path and stay in parity."""
+    M, N, K = 128, 192, 1100
     X, W, H = oracle.gen_problem(M, N, K, seed=12)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)
     r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=10)
@@ -465,17 +465,17 @@ def test_k_above_fused_limit_takes_unfused_path(ng, oracle):
 
 
 def test_random_shape_sweep(ng, oracle):
-    """seeded sweep over ragged shapes across every kernel instantiation (K tiles 1/2/4/8, NB 5..8, operator path),
+    """seeded sweep over ragged shapes across every kernel instantiation (split kernel, K tiles 1/2/4/8, NB 5..8, wave pairs NBH 5..8, operator path),
     automatic split counts, 3 iterations each, against the oracle"""
     rng = np.random.default_rng(2024)
-    ks = [1, 7, 32, 33, 64, 100, 128, 200, 256, 257, 320, 333, 400, 448, 512, 513, 640]
+    ks = [1, 7, 32, 33, 64, 100, 128, 200, 256, 257, 320, 333, 400, 448, 512, 513, 640, 700, 896, 1000, 1024, 1025]
     for K in ks:
         M = int(rng.integers(1, 700))
         N = int(rng.integers(1, 900))
         X, W, H = oracle.gen_problem(M, N, K, seed=int(rng.integers(0, 1 << 30)))
         Wm, Hm = ng.Matrix(W), ng.Matrix(H)
         r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=3)
-        assert r["path_used"] == (ng.PATH_FUSED if K <= 512 else ng.PATH_UNFUSED), (M, N, K)
+        assert r["path_used"] == (ng.PATH_FUSED if K <= 1024 else ng.PATH_UNFUSED), (M, N, K)
         Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 3, 25)
         eW, eH = oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr)
         assert eW < 1e-5 and eH < 1e-5 and np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all(), (M, N, K, eW, eH)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nmf_gpu_amd as ng
 shapes = [(8192, 16384, 512), (8192, 131072, 512), (4096, 65536, 128), (4096, 65536, 64), (4096, 262144, 256), (4096, 32768, 256), (4096, 65536, 384)]
 if len(sys.argv) > 1:
-    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+    shapes = [tuple(int(v) for v in a.replace("x", ",").split(",")) for a in sys.argv[1:]]
 rng = np.random.default_rng(0)
 for (M, N, K) in shapes:
     s = ng.Solver(M, N, K)
