@@ -31,8 +31,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU 
 # the committed profile of this command and is reported under "pmc_static" with its source, never mixed into live values.
 PMC_STATIC = {(4096, 65536, 256): {
     "source": "profiles/r02_pmc_summary.md: rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (not this run)",
-    "hbm_bytes_per_launch": {"H": 1.368e9, "W": 1.209e9}, "algorithmic_bytes_per_launch": 1.21e9,
-    "mfma_busy_frac_of_simd_cycles": {"H": 0.912, "W": 0.917}}}
+    "hbm_bytes_per_launch": {"H": 1.369e9, "W": 1.208e9}, "algorithmic_bytes_per_launch": 1.21e9,
+    "mfma_busy_frac_of_simd_cycles": {"H": 0.910, "W": 0.917}}}
 
 
 def _draw(rs, rows, cols, keep=True):

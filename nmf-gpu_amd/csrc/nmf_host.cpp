@@ -305,7 +305,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     if (path == NMF_PATH_FUSED) {
         HIPCHK(hipMalloc((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups));
         HIPCHK(hipMalloc((void **)&s->xc3, sizeof(double) * 3));
-        HIPCHK(hipMalloc((void **)&s->sum64, sizeof(double) * (size_t)s->Kp * (1 + kSum64Blocks)));
+        HIPCHK(hipMalloc((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks)));
         if (x_from) HIPCHK(hipMemcpyAsync(s->xc3, x_from->xc3, sizeof(double) * 3, hipMemcpyDeviceToDevice, s->stream));
         else HIPCHK(hipMemsetAsync(s->xc3, 0, sizeof(double) * 3, s->stream));
     }

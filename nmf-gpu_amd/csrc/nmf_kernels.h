@@ -105,7 +105,7 @@ hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp
 //   * sum x log x - x and sum |x| depend on X alone: launch_x_consts, once per upload, fp64;
 //   * sum x log y and sum |x - y| need W*H: launch_check (the half-step kernels in CHECK mode: product 1 only, W*H never
 //     materialised), per-workgroup partial triples {sum x log2 y, sum |x - y|, 0} in `part`;
-//   * sum y = sum_k colsum(W)_k rowsum(H)_k needs no pass over M x N: launch_check_compose sums the factors in fp64 (the
+//   * sum y = sum_n sum_k colsum(W)_k H[k,n] needs no pass over M x N: launch_check_compose sums the factors in fp64 (the
 //     three terms cancel to 1e-2..1e-3 of their size, so fp32 normalisers would cost digits), adds the partials in fixed
 //     order and leaves {KL, sum|X-WH|, sum|X|} in out3.
 int        check_num_groups(int Np, int Kp);
@@ -116,10 +116,10 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
                         double *part, hipStream_t stream);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
 constexpr int kXConstGroups = 1024;     // partial triples of launch_x_consts
-constexpr int kSum64Blocks = 128;       // column blocks of the fp64 row sums of H
+constexpr int kSum64Blocks = 2048;      // workgroup partials of the weighted fp64 sum over H
 // xc3 <- {sum x log x - x, sum |x|, 0} over the n floats of X (zeros skipped); part: 3 * kXConstGroups doubles of scratch
 hipError_t launch_x_consts(const float *X, size_t n, double *part, double *xc3, hipStream_t stream);
-// scratch64: Kp + kSum64Blocks * Kp doubles
+// scratch64: Kp + kSum64Blocks doubles
 hipError_t launch_check_compose(const double *part, int ngroups, const float *W, const float *H, int Mp, int Np, int Kp,
                                 const double *xc3, double *scratch64, double *out3, hipStream_t stream);
 

@@ -193,36 +193,29 @@ __global__ __launch_bounds__(256) void colsum64_kernel(const float *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-// part[b][k] = sum over column block b of H[k, :]; threads run along k (coalesced), four columns in flight
-__global__ __launch_bounds__(256) void rowsum64_kernel(const float *__restrict__ H, int Kp, int Np, double *__restrict__ part) {
-    const int per = (Np + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int c0 = blockIdx.x * per, c1 = (c0 + per < Np) ? c0 + per : Np;
-    for (int k = threadIdx.x; k < Kp; k += 256) {
-        const float *__restrict__ a = H + (size_t)k;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int c = c0;
-        for (; c + 4 <= c1; c += 4) {
-            s0 += (double)a[(size_t)c * Kp]; s1 += (double)a[(size_t)(c + 1) * Kp];
-            s2 += (double)a[(size_t)(c + 2) * Kp]; s3 += (double)a[(size_t)(c + 3) * Kp];
-        }
-        for (; c < c1; ++c) s0 += (double)a[(size_t)c * Kp];
-        part[(size_t)blockIdx.x * Kp + k] = (s0 + s1) + (s2 + s3);
+// sum y = sum_n sum_k colsum(W)_k H[k, n]: one coalesced pass over H with the fp64 column sums of W as weights, fp64
+// accumulation per thread, one partial per workgroup (fixed grid: reproducible)
+__global__ __launch_bounds__(256) void ysum_kernel(const float *__restrict__ H, size_t n, int Kp, const double *__restrict__ wsum, double *__restrict__ ypart) {
+    extern __shared__ double wl[];
+    for (int k = threadIdx.x; k < Kp; k += 256) wl[k] = wsum[k];
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+        s0 += wl[i % (size_t)Kp] * (double)H[i];
+        s1 += wl[(i + stride) % (size_t)Kp] * (double)H[i + stride];
     }
+    if (i < n) s0 += wl[i % (size_t)Kp] * (double)H[i];
+    __shared__ double tot[3];
+    block_reduce3(s0 + s1, 0.0, 0.0, tot, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) ypart[blockIdx.x] = tot[0];
 }
-__global__ __launch_bounds__(256) void check_compose_kernel(const double *__restrict__ part, int ngroups, const double *__restrict__ wsum,
-                                                            const double *__restrict__ hpart, int nblk, int Kp, const double *__restrict__ xc3,
-                                                            double *__restrict__ out3) {
+__global__ __launch_bounds__(256) void check_compose_kernel(const double *__restrict__ part, int ngroups, const double *__restrict__ ypart, int ny,
+                                                            const double *__restrict__ xc3, double *__restrict__ out3) {
     double sy = 0.0, sxly = 0.0, sd = 0.0;
-    for (int k = threadIdx.x; k < Kp; k += 256) {
-        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;   // four loads in flight: one workgroup has nothing else to hide their latency
-        int b = 0;
-        for (; b + 4 <= nblk; b += 4) {
-            r0 += hpart[(size_t)b * Kp + k]; r1 += hpart[(size_t)(b + 1) * Kp + k];
-            r2 += hpart[(size_t)(b + 2) * Kp + k]; r3 += hpart[(size_t)(b + 3) * Kp + k];
-        }
-        for (; b < nblk; ++b) r0 += hpart[(size_t)b * Kp + k];
-        sy += wsum[k] * ((r0 + r1) + (r2 + r3));
-    }
+    for (int g = threadIdx.x; g < ny; g += 256) sy += ypart[g];
     for (int g = threadIdx.x; g < ngroups; g += 256) { sxly += part[3 * (size_t)g]; sd += part[3 * (size_t)g + 1]; }
     __shared__ double tot[3];
     block_reduce3(sy, sxly, sd, tot, threadIdx.x);
@@ -235,12 +228,14 @@ __global__ __launch_bounds__(256) void check_compose_kernel(const double *__rest
 }
 hipError_t launch_check_compose(const double *part, int ngroups, const float *W, const float *H, int Mp, int Np, int Kp,
                                 const double *xc3, double *scratch64, double *out3, hipStream_t stream) {
-    double *wsum = scratch64, *hpart = scratch64 + Kp;
-    int nblk = (Np + 63) / 64;
-    if (nblk > kSum64Blocks) nblk = kSum64Blocks;
+    double *wsum = scratch64, *ypart = scratch64 + Kp;
+    const size_t n = (size_t)Kp * Np;
+    size_t ny = (n + 256 * 32 - 1) / (256 * 32);
+    if (ny > (size_t)kSum64Blocks) ny = kSum64Blocks;
+    if (ny < 1) ny = 1;
     hipLaunchKernelGGL(colsum64_kernel, dim3(Kp), dim3(256), 0, stream, W, Mp, wsum);
-    hipLaunchKernelGGL(rowsum64_kernel, dim3(nblk), dim3(256), 0, stream, H, Kp, Np, hpart);
-    hipLaunchKernelGGL(check_compose_kernel, dim3(1), dim3(256), 0, stream, part, ngroups, wsum, hpart, nblk, Kp, xc3, out3);
+    hipLaunchKernelGGL(ysum_kernel, dim3((unsigned)ny), dim3(256), (size_t)Kp * sizeof(double), stream, H, n, Kp, wsum, ypart);
+    hipLaunchKernelGGL(check_compose_kernel, dim3(1), dim3(256), 0, stream, part, ngroups, ypart, (int)ny, xc3, out3);
     return hipGetLastError();
 }
 
