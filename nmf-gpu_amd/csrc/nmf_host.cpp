@@ -136,6 +136,8 @@ struct nmf_solver {
     hipGraph_t graph = nullptr, graph8 = nullptr;       // one iteration / kGraphBatch iterations
     hipGraphExec_t graph_exec = nullptr, graph8_exec = nullptr;
     bool graph_ready = false, graph8_ready = false;
+    bool graph8_failed = false;    // capturing kGraphBatch iterations failed once: replay single iterations, do not retry
+    bool timing_failed = false;    // a hipEvent of the piece timers could not be created: t[] would under-report
     // piece timing (eager, hipEvent pairs)
     bool timing = false;
     struct Ev { int which; hipEvent_t a, b; };
@@ -491,8 +493,12 @@ struct PieceScope {
     PieceScope(nmf_solver *s_, int which) : s(s_) {
         if (roctx().push && which >= 0 && which < 10) { roctx().push(kPieceName[which]); marked = true; }
         if (!s->timing) return;
-        nmf_solver::Ev e; e.which = which;
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        nmf_solver::Ev e; e.which = which; e.a = nullptr; e.b = nullptr;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) {
+            if (e.a) (void)hipEventDestroy(e.a);
+            s->timing_failed = true;      // reported by collect_timing
+            return;
+        }
         (void)hipEventRecord(e.a, s->stream);
         s->events.push_back(e);
         idx = (int)s->events.size() - 1;
@@ -511,6 +517,11 @@ static int collect_timing(nmf_solver *s, double t[10]) {
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     s->events.clear();
+    if (s->timing_failed) {
+        s->timing_failed = false;
+        set_err("piece timers: hipEventCreate failed, t[] is incomplete");
+        return NMF_ERR_HIP;
+    }
     return NMF_OK;
 }
 
@@ -800,8 +811,15 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
         int st = ensure_graph(s);
         if (st == NMF_OK) {
             int left = iters;
-            if (left >= kGraphBatch && ensure_graph8(s) == NMF_OK)
-                for (; left >= kGraphBatch; left -= kGraphBatch) HIPCHK(hipGraphLaunch(s->graph8_exec, s->stream));
+            if (left >= kGraphBatch && !s->graph8_failed) {
+                if (ensure_graph8(s) == NMF_OK) {
+                    for (; left >= kGraphBatch; left -= kGraphBatch) HIPCHK(hipGraphLaunch(s->graph8_exec, s->stream));
+                } else {   // keep going on single-iteration replays; leave no sticky error or half-open capture behind
+                    s->graph8_failed = true;
+                    (void)hipGetLastError();
+                    g_err[0] = 0;
+                }
+            }
             for (; left > 0; --left) HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));
             return NMF_OK;
         }
@@ -910,8 +928,10 @@ static int solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check,
     while (it < max_iter) {
         int n = max_iter - it;
         if (checks) { const int to_check = iter_check - (it % iter_check); if (to_check < n) n = to_check; }
+        if (timed && n > 256) n = 256;    // timed runs hold two hipEvents per piece: drain them block by block
         NMFCHK(nmf_solver_iterate(s, n));
         it += n;
+        if (timed && s->events.size() > 2048) NMFCHK(collect_timing(s, res ? res->t : nullptr));
         if (checks && (it % iter_check) == 0) {
             double cur = 0.0;
             NMFCHK(nmf_solver_check(s, &cur, &rl1));
