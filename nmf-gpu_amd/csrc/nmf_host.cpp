@@ -190,7 +190,7 @@ extern "C" int nmf_solver_create_batched(nmf_solver **out, int M, int N, int K, 
 // Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
 // launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
 // kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
-static int split_pad_k(int K) { return K <= 64 ? 64 : (K <= 128 ? 128 : 0); }
+static int split_pad_k(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : (K <= 128 ? 128 : 0)); }
 static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int kp = split_pad_k(K);
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
@@ -347,7 +347,7 @@ extern "C" int nmf_solver_path(const nmf_solver *s) { return s ? s->path : 0; }
 extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
-    else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kp / 64, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
+    else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KB=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kp / 32, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
     else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 64, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);

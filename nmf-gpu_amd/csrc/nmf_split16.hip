@@ -30,16 +30,20 @@ constexpr int kXs16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-st
 // NW = waves per workgroup = 32-row sub-images per superchunk (4, or 8 at K = 64: one workgroup then puts two waves on
 // every SIMD of its CU, and each fills the other's quotient / wait / barrier time with MFMAs -- what a second workgroup
 // per CU does for the 64-column kernel, for shapes with no more than one workgroup per CU to hand out).
-template <int NB, int NW, bool WSTEP, bool PARTIAL, int DIV, int OCC>
+// KB = K / 32 (1, 2, 4).  k index of product-1 step s in lane group kq: 4 RUN (s / RUN) + RUN kq + s % RUN with per-lane
+// contiguous runs of RUN = 16 (K >= 64: the map of nmf_fused16.hip) or 8 (K = 32: no zero padding up to 64 for the many NMF
+// problems with a few dozen components, the paper's R = 30 among them; product-1 LDS reads are then 2-way bank-conflicted).
+template <int KB, int NW, bool WSTEP, bool PARTIAL, int DIV, int OCC>
 __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = 64 * NB;
+    constexpr int K = 32 * KB;
+    constexpr int RUN = KB >= 2 ? 16 : 8;
     constexpr int VBUF = K * kLdv;   // one 32-wide sub-image
     constexpr int IMG = NW * VBUF;   // one superchunk
     constexpr int SH = NW / 4;       // sub-images staged per pass of the workgroup's 8 NW piece slots (32 slots per sub-image)
-    constexpr int N1 = 16 * NB;      // product-1 steps per 16-row tile
-    constexpr int NT = 4 * NB;       // 16 x 16 accumulator tiles
-    constexpr int NST = 2 * NB;      // staged 16-B pieces per thread per 32-row chunk
+    constexpr int N1 = 8 * KB;       // product-1 steps per 16-row tile
+    constexpr int NT = 2 * KB;       // 16 x 16 accumulator tiles
+    constexpr int NST = KB;          // staged 16-B pieces per thread per 32-row chunk
     constexpr int NPC = 4 * NST;     // ... per superchunk
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
@@ -73,17 +77,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
     // B operands of product 1: ub[s] = U(k(s, kq), q0 + j)
     float ub[N1];
     if (!WSTEP) {
-        const float *__restrict__ col = U + (size_t)(16 * kq) + (size_t)(q0 + j) * ldu;
+        const float *__restrict__ col = U + (size_t)(RUN * kq) + (size_t)(q0 + j) * ldu;
 #pragma unroll
-        for (int sb = 0; sb < NB; ++sb)
+        for (int sb = 0; sb < N1 / RUN; ++sb)
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
-                ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
+            for (int e4 = 0; e4 < RUN / 4; ++e4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 4 * RUN * sb + 4 * e4);
+                ub[RUN * sb + 4 * e4] = v[0]; ub[RUN * sb + 4 * e4 + 1] = v[1]; ub[RUN * sb + 4 * e4 + 2] = v[2]; ub[RUN * sb + 4 * e4 + 3] = v[3];
             }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(64 * (s >> 4) + 16 * kq + (s & 15)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(4 * RUN * (s / RUN) + RUN * kq + (s % RUN)) * ldu];
+    }
+
+    // The values this wave will update in the epilogue (tiles t = wave, wave + NW, ...: U(16 t + 4 kq + r, q0 + j)), fetched
+    // now so that the read-modify-write at the end does not wait for a global round trip on an otherwise idle CU
+    constexpr int NTW = (NT + NW - 1) / NW;
+    f32x4 uold[NTW];
+    if (!PARTIAL) {
+        const float *__restrict__ Ub = U;
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+            const int t = wave + NW * tt;
+            const int k = 16 * (t < NT ? t : 0) + 4 * kq;
+            if (!WSTEP) uold[tt] = *reinterpret_cast<const f32x4 *>(Ub + (size_t)k + (size_t)(q0 + j) * ldu);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) uold[tt][r] = Ub[(size_t)(q0 + j) + (size_t)(k + r) * ldu];
+            }
+        }
     }
 
     f32x4 acc[NT];
@@ -115,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         float *xt = smem + 2 * IMG + wave * kXs16Floats;   // no __restrict__: written and read back within the wave
         const int xw_off = WSTEP ? (lane >> 2) * 20 + 4 * (lane & 3) : (lane >> 3) * kXtLd + 4 * (lane & 7);
         const int xr_off = WSTEP ? 4 * kq * 20 + j : j * kXtLd + 4 * kq;
-        const int p1_off = 16 * kq * kLdv + j;     // + (64 (s>>4) + (s&15)) * kLdv + 16 T
+        const int p1_off = RUN * kq * kLdv + j;    // + (4 RUN (s / RUN) + s % RUN) * kLdv + 16 T
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
         f32x4 st[NPC];
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             constexpr int E1 = 2 * N1;
             float ar[D];
 #pragma unroll
-            for (int e = 0; e < D; ++e) ar[e] = lds_ld(b1 + (64 * ((e >> 1) >> 4) + ((e >> 1) & 15)) * kLdv + 16 * (e & 1));
+            for (int e = 0; e < D; ++e) ar[e] = lds_ld(b1 + (4 * RUN * ((e >> 1) / RUN) + ((e >> 1) % RUN)) * kLdv + 16 * (e & 1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(1);
             f32x4 s0, s1;
             constexpr int NLOAD = NPC + 2;
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
                 if (e + D < E1) {
                     const int en = e + D;
-                    ar[e % D] = lds_ld(b1 + (64 * ((en >> 1) >> 4) + ((en >> 1) & 15)) * kLdv + 16 * (en & 1));
+                    ar[e % D] = lds_ld(b1 + (4 * RUN * ((en >> 1) / RUN) + ((en >> 1) % RUN)) * kLdv + 16 * (en & 1));
                 }
                 if (!LAST && e >= G && e % G == 0 && e / G - 1 < NLOAD) {
                     const int l = e / G - 1;
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             float *__restrict__ Uo = a.U_out + (size_t)b * ustride;
             if (!WSTEP) {
                 float *p = Uo + (size_t)k + (size_t)(q0 + j) * ldu;
-                f32x4 u = *reinterpret_cast<const f32x4 *>(p);
+                f32x4 u = uold[tt];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u[e] = u[e] * (sum[e] / nrm_l[k + e]);
                 *reinterpret_cast<f32x4 *>(p) = u;
@@ -327,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float *p = Uo + (size_t)(q0 + j) + (size_t)(k + r) * ldu;
-                    *p = *p * (sum[r] / nrm_l[k + r]);
+                    *p = uold[tt][r] * (sum[r] / nrm_l[k + r]);
                 }
             }
         }
@@ -362,8 +384,13 @@ __global__ __launch_bounds__(256) void split_apply_kernel(float *__restrict__ U,
         f32x4 u = *reinterpret_cast<const f32x4 *>(Ub + i);
         if (WSTEP) {   // W (Mp x Kp): the four elements share column k (Mp % 4 == 0)
             const int k = (int)(i / (size_t)Mp);
-            float n = vb[k];
-            for (int sp = 1; sp < nsplit; ++sp) n += vb[(size_t)sp * Kp + k];
+            float n = vb[k];              // same fixed order as slab_sum4, four loads in flight
+            int sp = 1;
+            for (; sp + 4 <= nsplit; sp += 4) {
+                const float a0 = vb[(size_t)sp * Kp + k], a1 = vb[(size_t)(sp + 1) * Kp + k], a2 = vb[(size_t)(sp + 2) * Kp + k], a3 = vb[(size_t)(sp + 3) * Kp + k];
+                n += a0; n += a1; n += a2; n += a3;
+            }
+            for (; sp < nsplit; ++sp) n += vb[(size_t)sp * Kp + k];
             n = clamp_eps(n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = u[e] * (s[e] / n);
@@ -390,7 +417,7 @@ hipError_t launch_split_apply(float *U, const float *partials, const float *vpar
     return hipGetLastError();
 }
 
-template <int NB, int NW, int OCC>
+template <int KB, int NW, int OCC>
 static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t stream) {
     const int Q = wstep ? a.Mv : a.Nv;   // the column groups beyond hold zero padding only: it stays zero without being touched
     const dim3 grid((unsigned)((Q / 16) * a.nsplit), (unsigned)a.batch), block(64 * NW);
@@ -404,22 +431,22 @@ static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t s
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
     if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, false, 1, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, true, 1, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, false, 1, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, true, 1, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 1, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 1, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 1, OCC>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 1, OCC>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, false, 0, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, false, true, 0, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, false, 0, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<NB, NW, true, true, 0, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 0, OCC>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 0, OCC>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 0, OCC>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 0, OCC>);
     }
 #undef NMF_LAUNCH_S16
     return hipGetLastError();
 }
 
 size_t split_step_lds_bytes(int Kp, int nw) { return ((size_t)2 * nw * Kp * kLdv + nw * kXs16Floats) * sizeof(float); }
-bool split_step_supports(int Kp) { return Kp == 64 || Kp == 128; }
+bool split_step_supports(int Kp) { return Kp == 32 || Kp == 64 || Kp == 128; }
 
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream) {
     const int nw = wstep ? a.nw_w : a.nw_h;
@@ -430,8 +457,9 @@ hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream)
     if (a.nsplit < 1 || a.batch < 1 || (partial && (!a.partials || !a.vpart)) || (!partial && !a.U_out)) return hipErrorInvalidValue;
     if ((size_t)a.Mp * (size_t)a.Kp >= ((size_t)1 << 30) || (size_t)a.Kp * (size_t)a.Np >= ((size_t)1 << 30)) return hipErrorInvalidValue;   // 32-bit lane offsets
     switch (a.Kp) {
-        case 64:  return nw == 8 ? launch_split_k16<1, 8, 2>(a, wstep, stream) : launch_split_k16<1, 4, 2>(a, wstep, stream);
-        case 128: return launch_split_k16<2, 4, 1>(a, wstep, stream);
+        case 32:  return launch_split_k16<1, 4, 2>(a, wstep, stream);
+        case 64:  return nw == 8 ? launch_split_k16<2, 8, 2>(a, wstep, stream) : launch_split_k16<2, 4, 2>(a, wstep, stream);
+        case 128: return launch_split_k16<4, 4, 1>(a, wstep, stream);
         default:  return hipErrorInvalidValue;
     }
 }
