@@ -133,10 +133,11 @@ struct nmf_solver {
     float *staging = nullptr;      // unpadded upload/download staging (max of the three matrices)
     size_t staging_count = 0;
     // graph
-    hipGraph_t graph = nullptr, graph8 = nullptr;       // one iteration / kGraphBatch iterations
-    hipGraphExec_t graph_exec = nullptr, graph8_exec = nullptr;
-    bool graph_ready = false, graph8_ready = false;
-    bool graph8_failed = false;    // capturing kGraphBatch iterations failed once: replay single iterations, do not retry
+    // captured iterations: one graph per batch size (kGraphIters); a replay costs 10-16 us of host / launch time whatever it
+    // holds, which is a third of a small problem's iteration, so long runs replay 32 iterations at a time
+    struct Level { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; bool ready = false, failed = false; };
+    Level level[3];
+    bool graph_ready = false;      // the single-iteration graph (level 2) exists: capture works for this solver
     bool timing_failed = false;    // a hipEvent of the piece timers could not be created: t[] would under-report
     // piece timing (eager, hipEvent pairs)
     bool timing = false;
@@ -320,13 +321,19 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     return NMF_OK;
 }
 
+static void drop_graphs(nmf_solver *s) {
+    for (auto &l : s->level) {
+        if (l.e) (void)hipGraphExecDestroy(l.e);
+        if (l.g) (void)hipGraphDestroy(l.g);
+        l = nmf_solver::Level();
+    }
+    s->graph_ready = false;
+}
+
 extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
-    if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
-    if (s->graph8) (void)hipGraphDestroy(s->graph8);
+    drop_graphs(s);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     float *bufs[] = {s->W, s->H, s->x_shared ? nullptr : s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->vpart, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
     for (float *b : bufs) if (b) (void)hipFree(b);
@@ -443,14 +450,7 @@ extern "C" int nmf_solver_set_active(nmf_solver *s, const int *flags) {
     if (!s) return NMF_ERR_ARG;
     if (!flags && !s->active_d) return NMF_OK;
     if (!s->active_d) {   // the graphs captured so far hold a null flag pointer
-        if (s->graph_ready || s->graph8_ready) {
-            if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-            if (s->graph) (void)hipGraphDestroy(s->graph);
-            if (s->graph8_exec) (void)hipGraphExecDestroy(s->graph8_exec);
-            if (s->graph8) (void)hipGraphDestroy(s->graph8);
-            s->graph = s->graph8 = nullptr; s->graph_exec = s->graph8_exec = nullptr;
-            s->graph_ready = s->graph8_ready = false;
-        }
+        drop_graphs(s);
         HIPCHK(hipMalloc((void **)&s->active_d, sizeof(int) * (size_t)s->batch));
     }
     std::vector<int> f((size_t)s->batch, 1);
@@ -755,9 +755,8 @@ extern "C" int nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size
     return NMF_OK;
 }
 
-// cuda/nmf.cu:100-115: capture one iteration, replay it.  A second graph holds kGraphBatch iterations: a graph
-// replay costs ~10-16 us of host/launch time, which is most of a small problem's iteration (cfg2: ~70 us).
-constexpr int kGraphBatch = 8;
+// cuda/nmf.cu:100-115: capture iterations, replay them.
+constexpr int kGraphIters[3] = {32, 8, 1};
 static int capture_graph(nmf_solver *s, int iterations, hipGraph_t *graph, hipGraphExec_t *exec) {
     const double t0 = now_s();
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -775,16 +774,12 @@ static int capture_graph(nmf_solver *s, int iterations, hipGraph_t *graph, hipGr
     s->t_setup += now_s() - t0;
     return NMF_OK;
 }
-static int ensure_graph(nmf_solver *s) {
-    if (s->graph_ready) return NMF_OK;
-    NMFCHK(capture_graph(s, 1, &s->graph, &s->graph_exec));
-    s->graph_ready = true;
-    return NMF_OK;
-}
-static int ensure_graph8(nmf_solver *s) {
-    if (s->graph8_ready) return NMF_OK;
-    NMFCHK(capture_graph(s, kGraphBatch, &s->graph8, &s->graph8_exec));
-    s->graph8_ready = true;
+static int ensure_level(nmf_solver *s, int li) {
+    nmf_solver::Level &l = s->level[li];
+    if (l.ready) return NMF_OK;
+    NMFCHK(capture_graph(s, kGraphIters[li], &l.g, &l.e));
+    l.ready = true;
+    if (li == 2) s->graph_ready = true;
     return NMF_OK;
 }
 
@@ -808,19 +803,20 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
             s->normW_fresh = true;
         }
         if (!lean) s->normW_fresh = false;
-        int st = ensure_graph(s);
+        int st = ensure_level(s, 2);
         if (st == NMF_OK) {
             int left = iters;
-            if (left >= kGraphBatch && !s->graph8_failed) {
-                if (ensure_graph8(s) == NMF_OK) {
-                    for (; left >= kGraphBatch; left -= kGraphBatch) HIPCHK(hipGraphLaunch(s->graph8_exec, s->stream));
-                } else {   // keep going on single-iteration replays; leave no sticky error or half-open capture behind
-                    s->graph8_failed = true;
+            for (int li = 0; li < 3; ++li) {
+                const int n = kGraphIters[li];
+                if (left < n || s->level[li].failed) continue;
+                if (ensure_level(s, li) != NMF_OK) {   // keep going on the shorter graphs; leave no sticky error or half-open capture behind
+                    s->level[li].failed = true;
                     (void)hipGetLastError();
                     g_err[0] = 0;
+                    continue;
                 }
+                for (; left >= n; left -= n) HIPCHK(hipGraphLaunch(s->level[li].e, s->stream));
             }
-            for (; left > 0; --left) HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));
             return NMF_OK;
         }
         // capture unavailable (e.g. a collective that cannot be captured): fall back to eager launches

@@ -11,7 +11,7 @@ s = ng.Solver(M, N, K, use_graph=bool(graph), split_kernel=sk, nsplit_h=nh, nspl
 s.upload(None, None, np.asfortranarray(rng.random((M, N), dtype=np.float32)))
 for b in range(batch):
     s.upload_pair(b, np.asfortranarray(rng.random((M, K), dtype=np.float32)), np.asfortranarray(rng.random((K, N), dtype=np.float32)))
-s.iterate(16); s.sync()
+s.iterate(41); s.sync()
 t0 = time.perf_counter(); s.iterate(iters); s.sync(); dt = time.perf_counter() - t0
 print(f"({M},{N},{K}) graph={graph} split={s.uses_split_kernel} nsplit=({nh},{nw}) batch={batch}: {iters} iterations {dt * 1e3:.2f} ms = {iters * batch / dt:.0f} it/s "
       f"({dt / iters * 1e6:.1f} us per launch set, {8 * M * N * K * iters * batch / dt / 1e12:.2f} TF)")
