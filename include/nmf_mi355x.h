@@ -36,6 +36,8 @@ typedef struct {
 #define NMF_EPS ((float)(2.2204E-16))
 /* cuda/nmf.cu:9 */
 #define NMF_ITER_CHECK_DEFAULT 25
+/* nmf_opts.use_graph: let the library decide between hipGraph replay and eager launches */
+#define NMF_GRAPH_AUTO 2
 
 /* status codes (the reference has none: it prints and exit()s, error-check.hpp:12-17) */
 enum {
@@ -90,7 +92,11 @@ typedef struct {
     int   iter_check;       /* cuda/nmf.cu:9; <= 0 -> NMF_ITER_CHECK_DEFAULT */
     int   verbose;          /* README.md:54 */
     int   path;             /* NMF_PATH_* */
-    int   use_graph;        /* 1: replay one captured hipGraph per iteration (cuda/nmf.cu:100-115) */
+    int   use_graph;        /* NMF_GRAPH_AUTO (default): the resident solver replays captured hipGraphs; a one-shot update_div /
+                             * update_div_ex call does too unless the whole run is shorter than capturing is worth (8*M*N*K*max_iter
+                             * < 2e12 flop), where it launches eagerly; 1: replay captured hipGraphs of 32 / 8 / 1 iterations
+                             * (cuda/nmf.cu:100-115); 0: eager launches with a hipEvent pair around every piece (fills t[2..7]);
+                             * -1: eager launches, untimed */
     int   device;           /* HIP device ordinal, -1 = current */
     void *stream;           /* hipStream_t to run on, NULL = library-owned stream */
     void *comm;             /* nmf_comm* for an N-sharded run (see nmf_comm_*), NULL = single GPU */

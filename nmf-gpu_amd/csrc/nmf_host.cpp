@@ -77,7 +77,7 @@ extern "C" void nmf_default_opts(nmf_opts *o) {
     o->iter_check = NMF_ITER_CHECK_DEFAULT;    // cuda/nmf.cu:9
     o->verbose = 0;
     o->path = NMF_PATH_AUTO;
-    o->use_graph = 1;
+    o->use_graph = NMF_GRAPH_AUTO;
     o->device = -1;
     o->stream = nullptr;
     o->comm = nullptr;
@@ -110,6 +110,7 @@ struct nmf_solver {
     int nw_h = 4, nw_w = 4;        // waves per workgroup of the two half-steps (8 where K = 64 and the reduction length allows)
     float *vpart = nullptr;        // [batch][ns][Kp] per-split sums of the streamed factor
     int *active_d = nullptr;       // [batch] device flags, nullptr = all pairs iterate
+    int *active_own = nullptr;     // ... when allocated after creation (set_active on an unbatched solver), outside the arena
     bool x_shared = false;         // X belongs to another solver (update_div_restarts lanes)
     bool normW_fresh = false;      // normW = max(colsum(W), EPS) of the current W (left by the W-step's apply kernel): the H-step
                                    // may skip its column-sum launch.  Cleared by everything else that writes W.
@@ -126,7 +127,10 @@ struct nmf_solver {
     float *vsum_part = nullptr;    // nsplit_w x Kp row sums of H per split, written by the W-step kernel (FusedArgs::vsum_part)
     float *psum = nullptr;         // Mp*Kp + Kp floats: [sum_g Z*H' ; rowsum(H)] (all-reduce operand)
     float *psum_owned = nullptr;   // the allocation behind psum unless the caller supplied one
-    double *chk_part = nullptr, *chk_out = nullptr, *chk_host = nullptr;
+    void *arena = nullptr;         // the one device allocation behind every buffer below (Arena)
+    double *chk_part = nullptr, *chk_out = nullptr;
+    std::vector<double> chk_host;  // 3 doubles per pair (pageable: a pinned allocation costs more than a lifetime of 24-byte copies)
+    bool xc_valid = false;         // xc3 holds the X-only terms of the check for the X now resident (computed at the first check)
     double *xc_part = nullptr, *xc3 = nullptr, *sum64 = nullptr;   // the check's X-only terms and fp64 factor sums (launch_x_consts / launch_check_compose)
     int chk_groups = 0;
     float *Z = nullptr, *WtZ = nullptr, *ZHt = nullptr;   // unfused temporaries (cuda/nmf.cu:94-96)
@@ -146,13 +150,31 @@ struct nmf_solver {
     double t_setup = 0.0;
 };
 
+// Every device buffer of a solver comes out of ONE allocation: a drop-in update_div call creates and destroys a solver, and a
+// dozen hipMalloc / hipFree pairs were a millisecond of a 12 ms call at cfg2.  Buffers are registered while the shapes are
+// worked out and carved (256-byte aligned) when the total is known.
+struct Arena {
+    struct Req { void **p; size_t bytes; bool zero; };
+    std::vector<Req> reqs;
+    void reserve(void **p, size_t bytes, bool zero = false) { *p = nullptr; if (bytes) reqs.push_back({p, bytes, zero}); }
+    int commit(void **base_out, hipStream_t st) {
+        size_t total = 0;
+        for (auto &r : reqs) total += (r.bytes + 255) & ~(size_t)255;
+        char *base = nullptr;
+        HIPCHK(hipMalloc((void **)&base, total ? total : 256));
+        *base_out = base;
+        size_t off = 0;
+        for (auto &r : reqs) {
+            *r.p = base + off;
+            if (r.zero) HIPCHK(hipMemsetAsync(base + off, 0, r.bytes, st));
+            off += (r.bytes + 255) & ~(size_t)255;
+        }
+        return NMF_OK;
+    }
+};
+
 // launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
 constexpr int kMaxRowsApplyColsum = 65536;
-
-static int dev_alloc(float **p, size_t count) {
-    HIPCHK(hipMalloc((void **)p, count * sizeof(float)));
-    return NMF_OK;
-}
 
 static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
     // workgroups per split-less launch = ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU),
@@ -233,25 +255,23 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         s->Kp = pad32(K);
     }
     s->path = path;
-    s->use_graph = o.use_graph;
+    s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
     s->fast_divide = o.fast_divide;
     s->comm = (nmf_comm *)o.comm;
     if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
     const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
-    NMFCHK(dev_alloc(&s->W, mk * batch));
-    NMFCHK(dev_alloc(&s->H, kn * batch));
+    Arena ar;
+    bool zero_slabs = false;
+    ar.reserve((void **)&s->W, mk * batch * sizeof(float), true);
+    ar.reserve((void **)&s->H, kn * batch * sizeof(float), true);
     if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
-    else NMFCHK(dev_alloc(&s->X, mn));
-    HIPCHK(hipMemsetAsync(s->W, 0, mk * batch * sizeof(float), s->stream));
-    HIPCHK(hipMemsetAsync(s->H, 0, kn * batch * sizeof(float), s->stream));
-    if (!x_from) HIPCHK(hipMemsetAsync(s->X, 0, mn * sizeof(float), s->stream));
-    NMFCHK(dev_alloc(&s->normW, (size_t)s->Kp));
-    NMFCHK(dev_alloc(&s->normH, (size_t)s->Kp));
-    NMFCHK(dev_alloc(&s->rowpart, (size_t)row_sum_blocks(s->Np) * s->Kp));
-    NMFCHK(dev_alloc(&s->psum_owned, mk + (size_t)s->Kp));
-    s->psum = s->psum_owned;
+    else ar.reserve((void **)&s->X, mn * sizeof(float), true);
+    ar.reserve((void **)&s->normW, ((size_t)s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->normH, ((size_t)s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->rowpart, ((size_t)row_sum_blocks(s->Np) * s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->psum_owned, (mk + (size_t)s->Kp) * sizeof(float));
     if (s->split) {
         // eight waves per workgroup (two per SIMD from a single workgroup per CU) where K = 64 leaves the LDS for eight sub-images
         // (measured: 3 % on cfg2 alone, but 17 % slower than two independent four-wave workgroups per CU once a batch fills
@@ -268,12 +288,10 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         s->nsplit_h = s->ns_h; s->nsplit_w = s->ns_w;
         size_t pc = (size_t)s->ns_w * mk;                  // the W-step may always need slabs (sharded runs)
         if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
-        NMFCHK(dev_alloc(&s->partials, pc * batch));
-        // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
-        HIPCHK(hipMemsetAsync(s->partials, 0, pc * batch * sizeof(float), s->stream));
-        HIPCHK(hipMemsetAsync(s->psum_owned, 0, (mk + (size_t)s->Kp) * sizeof(float), s->stream));
+        ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
+        zero_slabs = true;   // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
         const int nsm = s->ns_h > s->ns_w ? s->ns_h : s->ns_w;
-        NMFCHK(dev_alloc(&s->vpart, (size_t)nsm * s->Kp * batch));
+        ar.reserve((void **)&s->vpart, ((size_t)nsm * s->Kp * batch) * sizeof(float));
         s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else if (path == NMF_PATH_FUSED) {
         const int qg = fused_cols_per_group(s->Kp);
@@ -284,38 +302,39 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         size_t pc = 0;
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
         if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
-        NMFCHK(dev_alloc(&s->partials, pc));
-        if (s->nsplit_w > 1 && fused_streams_vsum(s->Mp, s->Kp)) NMFCHK(dev_alloc(&s->vsum_part, (size_t)s->nsplit_w * s->Kp));
+        ar.reserve((void **)&s->partials, (pc) * sizeof(float));
+        if (s->nsplit_w > 1 && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp) * sizeof(float));
         s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else {
-        NMFCHK(dev_alloc(&s->Z, mn));
-        NMFCHK(dev_alloc(&s->WtZ, kn));
-        NMFCHK(dev_alloc(&s->ZHt, mk));
+        ar.reserve((void **)&s->Z, (mn) * sizeof(float));
+        ar.reserve((void **)&s->WtZ, (kn) * sizeof(float));
+        ar.reserve((void **)&s->ZHt, (mk) * sizeof(float));
         s->nsplit_w = 16;                                  // split-K slabs for the Z*H' GEMM
-        NMFCHK(dev_alloc(&s->partials, (size_t)s->nsplit_w * mk));
+        ar.reserve((void **)&s->partials, ((size_t)s->nsplit_w * mk) * sizeof(float));
         s->chk_groups = reduce_num_groups(mn);
     }
-    HIPCHK(hipMalloc((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups));
-    HIPCHK(hipMalloc((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch));
-    HIPCHK(hipHostMalloc((void **)&s->chk_host, sizeof(double) * 3 * (size_t)batch, hipHostMallocDefault));
-    if (batch > 1) {   // the flag array exists from the start, so that captured graphs never hold a stale null pointer
-        HIPCHK(hipMalloc((void **)&s->active_d, sizeof(int) * (size_t)batch));
-        std::vector<int> ones((size_t)batch, 1);
-        HIPCHK(hipMemcpyAsync(s->active_d, ones.data(), sizeof(int) * (size_t)batch, hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
-    }
-    HIPCHK(hipMalloc((void **)&s->range_flag, sizeof(unsigned)));
+    ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups);
+    ar.reserve((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch);
+    s->chk_host.assign(3 * (size_t)batch, 0.0);
+    if (batch > 1) ar.reserve((void **)&s->active_d, sizeof(int) * (size_t)batch);   // from the start: captured graphs never hold a stale null pointer
+    ar.reserve((void **)&s->range_flag, sizeof(unsigned));
     if (path == NMF_PATH_FUSED) {
-        HIPCHK(hipMalloc((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups));
-        HIPCHK(hipMalloc((void **)&s->xc3, sizeof(double) * 3));
-        HIPCHK(hipMalloc((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks)));
-        if (x_from) HIPCHK(hipMemcpyAsync(s->xc3, x_from->xc3, sizeof(double) * 3, hipMemcpyDeviceToDevice, s->stream));
-        else HIPCHK(hipMemsetAsync(s->xc3, 0, sizeof(double) * 3, s->stream));
+        ar.reserve((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups);
+        ar.reserve((void **)&s->xc3, sizeof(double) * 3, true);
+        ar.reserve((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks));
     }
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
     if ((size_t)K * N > s->staging_count) s->staging_count = (size_t)K * N;
-    NMFCHK(dev_alloc(&s->staging, s->staging_count));
+    ar.reserve((void **)&s->staging, s->staging_count * sizeof(float));
+    for (auto &r : ar.reqs) if (zero_slabs && (r.p == (void **)&s->partials || r.p == (void **)&s->psum_owned)) r.zero = true;
+    NMFCHK(ar.commit(&s->arena, s->stream));
+    s->psum = s->psum_owned;
+    if (x_from && s->xc3) { HIPCHK(hipMemcpyAsync(s->xc3, x_from->xc3, sizeof(double) * 3, hipMemcpyDeviceToDevice, s->stream)); s->xc_valid = x_from->xc_valid; }
+    if (batch > 1) {
+        std::vector<int> ones((size_t)batch, 1);
+        HIPCHK(hipMemcpyAsync(s->active_d, ones.data(), sizeof(int) * (size_t)batch, hipMemcpyHostToDevice, s->stream));
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->t_setup = now_s() - t0;
     return NMF_OK;
@@ -335,16 +354,8 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_graphs(s);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    float *bufs[] = {s->W, s->H, s->x_shared ? nullptr : s->X, s->normW, s->normH, s->rowpart, s->partials, s->vsum_part, s->vpart, s->psum_owned, s->Z, s->WtZ, s->ZHt, s->staging};
-    for (float *b : bufs) if (b) (void)hipFree(b);
-    if (s->chk_part) (void)hipFree(s->chk_part);
-    if (s->chk_out) (void)hipFree(s->chk_out);
-    if (s->chk_host) (void)hipHostFree(s->chk_host);
-    if (s->range_flag) (void)hipFree(s->range_flag);
-    if (s->xc_part) (void)hipFree(s->xc_part);
-    if (s->xc3) (void)hipFree(s->xc3);
-    if (s->sum64) (void)hipFree(s->sum64);
-    if (s->active_d) (void)hipFree(s->active_d);
+    if (s->arena) (void)hipFree(s->arena);
+    if (s->active_own) (void)hipFree(s->active_own);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -379,7 +390,7 @@ static int upload_one(nmf_solver *s, float *dst, int rows_p, int cols_p, const f
     if (dst == s->W) s->normW_fresh = false;
     if (is_x) HIPCHK(hipMemsetAsync(s->range_flag, 0, sizeof(unsigned), s->stream));
     HIPCHK(launch_pad_copy(dst, rows_p, cols_p, d, rows, cols, /*clamp=*/true, is_x ? s->range_flag : nullptr, s->stream));
-    if (is_x && s->xc3) HIPCHK(launch_x_consts(s->X, (size_t)s->Mp * s->Np, s->xc_part, s->xc3, s->stream));
+    if (is_x) s->xc_valid = false;   // the X-only terms of the check are summed when a check first asks for them
     if (is_x) {
         unsigned flag = 1;
         HIPCHK(hipMemcpyAsync(&flag, s->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
@@ -449,9 +460,10 @@ extern "C" int nmf_solver_download_pair(nmf_solver *s, int b, float *W, float *H
 extern "C" int nmf_solver_set_active(nmf_solver *s, const int *flags) {
     if (!s) return NMF_ERR_ARG;
     if (!flags && !s->active_d) return NMF_OK;
-    if (!s->active_d) {   // the graphs captured so far hold a null flag pointer
+    if (!s->active_d) {   // batch == 1: a flag for the one pair; the graphs captured so far hold a null flag pointer
         drop_graphs(s);
-        HIPCHK(hipMalloc((void **)&s->active_d, sizeof(int) * (size_t)s->batch));
+        HIPCHK(hipMalloc((void **)&s->active_own, sizeof(int) * (size_t)s->batch));
+        s->active_d = s->active_own;
     }
     std::vector<int> f((size_t)s->batch, 1);
     if (flags) for (int b = 0; b < s->batch; ++b) f[(size_t)b] = flags[b] ? 1 : 0;
@@ -846,6 +858,12 @@ extern "C" int nmf_solver_iterate_timed(nmf_solver *s, int iters, double t[10]) 
 }
 
 // KL / rel-L1 of the current state (reduce1d_div / reduce1d_diff, cuda/matrix.cu:505-640)
+static int ensure_x_consts(nmf_solver *s) {
+    if (s->xc_valid || !s->xc3) return NMF_OK;
+    HIPCHK(launch_x_consts(s->X, (size_t)s->Mp * s->Np, s->xc_part, s->xc3, s->stream));
+    s->xc_valid = true;
+    return NMF_OK;
+}
 static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
     if (!s || !sums || b < 0 || b >= s->batch) return NMF_ERR_ARG;
     hipStream_t st = s->stream;
@@ -853,6 +871,7 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
         PieceScope p(s, NMF_T_CHECK);
         if (s->path == NMF_PATH_FUSED) {
             const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
+            NMFCHK(ensure_x_consts(s));
             HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
             HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out, st));
         } else {
@@ -864,7 +883,7 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
         }
         if (s->comm) NMFCHK(nmf_comm_allreduce_f64(s->comm, s->chk_out, 3, st));
     }
-    HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->chk_host.data(), s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     sums[0] = s->chk_host[0]; sums[1] = s->chk_host[1]; sums[2] = s->chk_host[2];
     return NMF_OK;
@@ -876,15 +895,16 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     if (!s) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) { set_err("check_all: fused path only"); return NMF_ERR_UNSUPPORTED; }
     hipStream_t st = s->stream;
+    NMFCHK(ensure_x_consts(s));
     for (int b = 0; b < s->batch; ++b) {
         const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
         HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
         HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
     }
-    HIPCHK(hipMemcpyAsync(s->chk_host, s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->chk_host.data(), s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < s->batch; ++b) {
-        const double *v = s->chk_host + 3 * (size_t)b;
+        const double *v = s->chk_host.data() + 3 * (size_t)b;
         if (kl) kl[b] = v[0];
         if (rel_l1) rel_l1[b] = (v[2] > 0.0) ? v[1] / v[2] : 0.0;
     }
@@ -1119,6 +1139,10 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
             res->n_shards = 1; res->w_replicas_identical = 1;
         }
     }
+    // A one-shot call pays for capture and instantiation (1-2 ms) out of its own run time: worth it only for long runs -- every
+    // launch of this path outlasts its own host-side enqueue, so replay does not make a short run faster (cfg2, 200 iterations:
+    // 12.7 ms captured, 12.0 ms eager; the paper's shape 9.9 / 7.8 ms).  The resident solver (nmf_solver_*) keeps its graphs.
+    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12 && !o.comm) ? -1 : 1;
     nmf_solver *s = nullptr;
     NMFCHK(nmf_solver_create(&s, M, N, K, &o));
     int st = NMF_OK;
@@ -1313,7 +1337,7 @@ extern "C" void update_div(matrix W, matrix H, matrix X, float CONVERGE_THRESH, 
     o.converge_thresh = CONVERGE_THRESH;
     o.max_iter = max_iter;
     o.verbose = verbose;
-    o.use_graph = (t == nullptr) ? 1 : 0;   // timers requested: eager launches with per-piece hipEvents
+    o.use_graph = (t == nullptr) ? NMF_GRAPH_AUTO : 0;   // timers requested: eager launches with per-piece hipEvents
     nmf_result res;
     const int st = update_div_ex(W, H, X, &o, &res);
     if (st != NMF_OK) {

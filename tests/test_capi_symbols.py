@@ -145,7 +145,7 @@ def test_defaults_follow_reference_knobs(ng):
     o = _opts()
     ng.lib().nmf_default_opts(C.byref(o))
     assert o.max_iter == 200 and o.iter_check == 25 and o.converge_thresh == 0.0   # cuda/nmf.cu:9-11
-    assert o.use_graph == 1 and o.path == ng.PATH_AUTO
+    assert o.use_graph == 2 and o.path == ng.PATH_AUTO      # NMF_GRAPH_AUTO
     assert ng.lib().nmf_status_string(2) == b"dimensions do not agree"
 
 
