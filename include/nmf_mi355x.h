@@ -198,6 +198,9 @@ int  nmf_solver_download(nmf_solver *s, float *W, float *H);
 /* enqueue `iters` iterations (H half-step then W half-step each, cuda/nmf.cu:108-109) on the
  * solver's stream; does not synchronise. */
 int  nmf_solver_iterate(nmf_solver *s, int iters);
+/* capture and instantiate the hipGraphs that nmf_solver_iterate(s, iters) would replay, without running them (keeps the
+ * one-off capture cost out of a caller's timed region) */
+int  nmf_solver_prepare(nmf_solver *s, int iters);
 /* `iters` iterations launched eagerly with a hipEvent pair around every piece (the README's t[10], README.md:53):
  * adds the device seconds of each piece to t[NMF_T_H_STEP .. NMF_T_ALLREDUCE]; synchronises. */
 int  nmf_solver_iterate_timed(nmf_solver *s, int iters, double t[10]);

@@ -93,6 +93,7 @@ _SIGS = [
     ("nmf_solver_upload_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nmf_solver_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nmf_solver_iterate", C.c_int, [C.c_void_p, C.c_int]),
+    ("nmf_solver_prepare", C.c_int, [C.c_void_p, C.c_int]),
     ("nmf_solver_iterate_timed", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("nmf_solver_update_h", C.c_int, [C.c_void_p]),
     ("nmf_solver_update_w", C.c_int, [C.c_void_p]),
@@ -491,6 +492,10 @@ class Solver:
 
     def iterate(self, iters: int = 1):
         _chk(lib().nmf_solver_iterate(self._h, iters))
+
+    def prepare(self, iters: int):
+        """capture the hipGraphs an iterate(iters) call replays, without running them"""
+        _chk(lib().nmf_solver_prepare(self._h, iters))
 
     def iterate_timed(self, iters: int = 1) -> dict:
         """eager iterations with hipEvents around every piece; returns device seconds per piece name"""

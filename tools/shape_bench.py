@@ -10,8 +10,8 @@ for (M, N, K) in shapes:
     s = ng.Solver(M, N, K)
     s.upload(np.asfortranarray(rng.random((M, K), dtype=np.float32)), np.asfortranarray(rng.random((K, N), dtype=np.float32)),
              np.asfortranarray(rng.random((M, N), dtype=np.float32)))
-    s.iterate(5); s.sync()
-    t0 = time.perf_counter(); s.iterate(20); s.sync(); dt = (time.perf_counter() - t0) / 20
+    s.iterate(41); s.sync()          # every graph level captured, clocks settled
+    t0 = time.perf_counter(); s.iterate(64); s.sync(); dt = (time.perf_counter() - t0) / 64
     f = 4.0 * M * N * K
     if s.path == ng.PATH_FUSED:
         h, w = s.time_piece(2, 10), s.time_piece(3, 10)
