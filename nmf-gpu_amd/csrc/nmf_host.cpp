@@ -219,7 +219,11 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
     if (((size_t)M + 127) * kp >= ((size_t)1 << 30) || ((size_t)N + 127) * kp >= ((size_t)1 << 30)) return false;
     if (o.split_kernel > 0) return true;
-    return (size_t)M * (size_t)N <= ((size_t)1 << 26);
+    // measured crossover (tools/crossover.py, iteration time of both families over M x N from 2^22 to 2^26 elements): the split
+    // kernel is 5-26 % ahead up to 2^23 elements at K = 128 and 2^23-2^24 at K = 64 (a tie at 2^24), 3-14 % behind beyond; at
+    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25
+    const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : 23);
+    return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128: one
 // workgroup per CU is the target; a function of the shape alone, so that a batched run equals its sequential twin bit for bit

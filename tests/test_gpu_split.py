@@ -14,7 +14,8 @@ def _relF(oracle, a, b):
     return oracle.relF(a, b)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 96, 32), (100, 70, 17), (257, 130, 64), (33, 1, 1), (1, 33, 5), (300, 1000, 100), (129, 257, 128), (128, 128, 65)])
+@pytest.mark.parametrize("M,N,K", [(64, 96, 32), (100, 70, 17), (257, 130, 64), (33, 1, 1), (1, 33, 5), (1, 1, 1), (300, 1000, 100), (129, 257, 128), (128, 128, 65),
+                                   (60, 70000, 16), (70000, 60, 40), (5000, 7, 128)])
 def test_split_kernel_half_steps(ng, oracle, M, N, K):
     """one update_h then one update_w on ragged and degenerate sizes: the in-stream normalisers (colsum W, rowsum H) and
     the four-wave reduction must reproduce the oracle; the other factor must not be touched"""
@@ -55,7 +56,8 @@ def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
 
 def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
     for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), False),
-                            ((4096, 65536, 64), False)):
+                            ((4096, 65536, 64), False), ((4096, 4096, 128), False), ((4096, 2048, 128), True), ((4096, 8192, 64), False),
+                            ((512, 65536, 20), True)):
         s = ng.Solver(M, N, K)
         assert s.uses_split_kernel == want, (M, N, K)
         s.close()
