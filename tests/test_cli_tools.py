@@ -138,3 +138,25 @@ def test_in_library_driver_over_a_real_rccl_communicator_of_one_rank(ng, oracle)
     s.close(); c.close()
     assert oracle.relF(Wg, Wr) < 1e-5 and oracle.relF(Hg, Hr) < 1e-5
     assert ng.lib().nmf_worth_sharding(4096, 262144, 256, 8) == 1 and ng.lib().nmf_worth_sharding(1024, 4096, 64, 8) == 0
+
+
+@pytest.mark.gpu
+def test_multi_device_requests_that_cannot_be_met_are_refused(ng):
+    """n_devices beyond what is visible, shards without host data, more ranks than columns: a status, never a hang"""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    W, H, X = (ng.Matrix(rng.random(s, dtype=np.float32)) for s in ((64, 8), (8, 96), (64, 96)))
+    with pytest.raises(ng.NmfError) as e:
+        ng.update_div_ex(W, H, X, max_iter=2, n_devices=ng.device_count() + 1)
+    assert e.value.status == 1
+    with pytest.raises(ng.NmfError) as e:
+        ng.update_div_ex(W, H, X, max_iter=2, emulate_shards=9)
+    assert e.value.status == 1
+    Hs, Xs = ng.Matrix(rng.random((8, 2), dtype=np.float32)), ng.Matrix(rng.random((64, 2), dtype=np.float32))
+    with pytest.raises(ng.NmfError) as e:
+        ng.update_div_ex(W, Hs, Xs, max_iter=2, emulate_shards=3)       # 2 columns over 3 ranks
+    assert e.value.status == 1
+    r = ng.update_div_ex(W, H, X, max_iter=2, n_devices=1)
+    assert r["n_shards"] == 1 and r["w_replicas_identical"] == 1
+    r = ng.update_div_ex(W, H, X, max_iter=3, emulate_shards=2, converge_thresh=1e-30, iter_check=1)
+    assert r["n_shards"] == 2 and r["iterations"] == 3 and len(r["kl"]) == 4 and r["kl"][0] > r["kl"][-1]
