@@ -109,13 +109,13 @@ typedef struct {
                              * -1: always the full sequence (for A/B tests of the above);
                              * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
                              *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
-    int   restart_lanes;    /* update_div_restarts only.  0 = automatic: shapes the split kernel takes (K <= 128, see split_kernel)
+    int   restart_lanes;    /* update_div_restarts only.  0 = automatic: shapes the split kernel takes (K <= 256 and small enough, see split_kernel)
                              * run ALL restarts in every launch (the restart index is a grid dimension); other shapes iterate two
                              * initialisations side by side on their own streams unless one launch already fills the chip.
                              * n > 0: n stream lanes (1 = one restart after the other), never the batched grid */
     int   split_kernel;     /* which fused kernel family: 0 = automatic; 1 = the split kernel (four waves per 16 owned columns,
                              * normalisers summed in-stream, two to four launches per iteration: problems that do not fill
-                             * the chip, K <= 128); -1 = never (the 64-column kernel of the large configurations) */
+                             * the chip, K <= 256); -1 = never (the 64-column kernel of the large configurations) */
     int   n_devices;        /* update_div / update_div_ex with host matrices: how many GPUs of this node share the work (columns of
                              * X and H are sharded, W is replicated, one RCCL all-reduce of [Z*H' ; rowsum(H)] per iteration inside
                              * each device's hipGraph; one host thread per device, all inside the call).  0 = automatic: every visible
@@ -232,7 +232,7 @@ int  nmf_solver_partial_buffer(nmf_solver *s, float **dev_ptr, size_t *count);
  * its partial buffer, e.g. the storage of a torch tensor that torch.distributed will all-reduce */
 int  nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size_t count);
 /* B independent (W, H) pairs against one X in every launch (multi-restart NMF, paper section 3.2; the restart index is a
- * grid dimension of the split kernel, K <= 128).  Pair b is addressed by the *_pair calls; upload / download / check
+ * grid dimension of the split kernel, K <= 256).  Pair b is addressed by the *_pair calls; upload / download / check
  * without a pair index act on pair 0.  `flags` (batch ints, host) freezes pairs whose flag is 0: they are skipped by
  * every later iterate (a converged restart stops exactly where a sequential update_div would). */
 int  nmf_solver_create_batched(nmf_solver **s, int M, int N, int K, int batch, const nmf_opts *opts);

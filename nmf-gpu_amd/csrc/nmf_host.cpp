@@ -213,7 +213,7 @@ extern "C" int nmf_solver_create_batched(nmf_solver **out, int M, int N, int K, 
 // Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
 // launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
 // kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
-static int split_pad_k(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : (K <= 128 ? 128 : 0)); }
+static int split_pad_k(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 256 ? 256 : 0))); }
 static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int kp = split_pad_k(K);
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
@@ -221,8 +221,8 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     if (o.split_kernel > 0) return true;
     // measured crossover (tools/crossover.py, iteration time of both families over M x N from 2^22 to 2^26 elements): the split
     // kernel is 5-26 % ahead up to 2^23 elements at K = 128 and 2^23-2^24 at K = 64 (a tie at 2^24), 3-14 % behind beyond; at
-    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25
-    const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : 23);
+    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25; at 128 < K <= 256 (one LDS image) 5-58 % ahead up to 2^22
+    const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : (kp == 128 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128: one
@@ -246,7 +246,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     // the split kernel streams whole superchunks of 128: zero padding is invariant under the updates and adds nothing to any sum
     s->Mp = s->split ? ((M + 127) & ~127) : pad32(M);
     s->Np = s->split ? ((N + 127) & ~127) : pad32(N);
-    if (batch > 1 && !s->split) { set_err("batched solvers need the split kernel (K <= 128)"); return NMF_ERR_UNSUPPORTED; }
+    if (batch > 1 && !s->split) { set_err("batched solvers need the split kernel (K <= 256)"); return NMF_ERR_UNSUPPORTED; }
     if (s->split) path = NMF_PATH_FUSED;
     // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
     const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
@@ -557,6 +557,8 @@ static SplitArgs split_args(nmf_solver *s) {
     a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
     a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
     a.nw_h = s->nw_h; a.nw_w = s->nw_w;
+    // K = 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
+    a.single_image = (s->Kp == 128 && s->batch > 1 && !getenv("NMF_SPLIT_DOUBLE")) || (s->Kp == 128 && getenv("NMF_SPLIT_SINGLE") != nullptr);
     a.Mv = (s->M + 31) & ~31; a.Nv = (s->N + 31) & ~31;
     a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np;
     a.active = s->active_d;
@@ -1251,8 +1253,12 @@ static int auto_lanes(const nmf_solver *s, int n_restarts) {
 // all B pairs (B x the workgroups; X tiles shared through L2), each pair iterating exactly as a sequential update_div on
 // it would -- same kernels, same split counts, hence the same bits -- and freezing at its own convergence check.
 constexpr int kMaxRestartBatch = 64;
-static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o, int M, int N, int K, int *best, double *kl) {
+static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl) {
     const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
+    nmf_opts o = o_in;
+    // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
+    // batch outlasts its own enqueue by far): 16 restarts x 200 iterations on the gold shape take 67 ms eagerly, 90 ms captured
+    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
     nmf_solver *s = nullptr;
     NMFCHK(nmf_solver_create_batched(&s, M, N, K, B, &o));
     int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);

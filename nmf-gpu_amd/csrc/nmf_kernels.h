@@ -73,13 +73,14 @@ struct SplitArgs {
     int nsplit;
     int nw_h, nw_w;           // waves per workgroup (4 or 8) of the H- and the W-step: reduction length % (32 nw) == 0; 8 needs Kp == 64
     int force_partial;        // 1: raw slab + sums even with nsplit == 1 (sharded runs: the all-reduce operand)
+    int single_image;         // Kp == 128 only: one LDS image instead of two (two workgroups per CU; same arithmetic).  Kp == 256 always runs so
     int batch;
     size_t strideW, strideH;  // floats between consecutive pairs
     const int *active;        // optional [batch] flags: 0 = leave this pair untouched (it has converged)
     int fast_divide, x_in_range;
 };
 bool       split_step_supports(int Kp);
-size_t     split_step_lds_bytes(int Kp, int nw);
+size_t     split_step_lds_bytes(int Kp, int nw, bool double_buffered);
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream);
 // q_valid: rows of W (W-step) / columns of H (H-step) that got a workgroup (SplitArgs::Mv / Nv); the rest is zero padding
 hipError_t launch_split_apply(float *U, const float *partials, const float *vpart, int nsplit, int Mp, int Np, int Kp, int q_valid, bool wstep,

@@ -33,7 +33,12 @@ constexpr int kXs16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-st
 // KB = K / 32 (1, 2, 4).  k index of product-1 step s in lane group kq: 4 RUN (s / RUN) + RUN kq + s % RUN with per-lane
 // contiguous runs of RUN = 16 (K >= 64: the map of nmf_fused16.hip) or 8 (K = 32: no zero padding up to 64 for the many NMF
 // problems with a few dozen components, the paper's R = 30 among them; product-1 LDS reads are then 2-way bank-conflicted).
-template <int KB, int NW, bool WSTEP, bool PARTIAL, int DIV, int OCC>
+// DB = false: ONE superchunk image in LDS instead of two.  The next image then cannot be written behind product 2; it goes
+// to LDS between two barriers after it (from the registers the loads of this iteration filled), which exposes ~4 NPC ds_writes
+// per superchunk -- and halves the LDS footprint: K = 128 fits two workgroups per CU (78 KiB each), which is what a batch of
+// restarts needs to overlap one workgroup's quotient / barrier / first-touch time with another's MFMAs, and K = 256 fits at all
+// (135 KiB).  Same arithmetic in the same order as DB = true: the choice may depend on the batch size.
+template <int KB, int NW, bool WSTEP, bool PARTIAL, int DIV, int OCC, bool DB = true>
 __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 32 * KB;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         // The X tile of superchunk s is loaded while s - 2 is being computed (one wave per SIMD has nobody to hide an L2
         // miss behind), parked in the wave's LDS patch at the end of that iteration, and read back in the accumulator
         // layout during s - 1, after that iteration's quotient and before its own parking.
-        float *xt = smem + 2 * IMG + wave * kXs16Floats;   // no __restrict__: written and read back within the wave
+        float *xt = smem + (DB ? 2 : 1) * IMG + wave * kXs16Floats;   // no __restrict__: written and read back within the wave
         const int xw_off = WSTEP ? (lane >> 2) * 20 + 4 * (lane & 3) : (lane >> 3) * kXtLd + 4 * (lane & 7);
         const int xr_off = WSTEP ? 4 * kq * 20 + j : j * kXtLd + 4 * kq;
         const int p1_off = RUN * kq * kLdv + j;    // + (4 RUN (s / RUN) + s % RUN) * kLdv + 16 T
@@ -220,8 +225,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         auto body = [&](int sc, auto last_tag, auto vs_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             const int rel = sc - sc_begin, par = rel & 1;
-            const float *__restrict__ vb = smem + par * IMG + wave * VBUF;
-            float *__restrict__ vn = smem + (par ^ 1) * IMG;
+            const float *__restrict__ vb = smem + (DB ? par * IMG : 0) + wave * VBUF;
+            float *__restrict__ vn = smem + (DB ? (par ^ 1) * IMG : 0);
             if (!LAST) { set_v(sc + 1); set_x(sc + 2 < sc_end ? sc + 2 : sc_last); }
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
@@ -236,7 +241,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
 #pragma unroll
             for (int e = 0; e < E1; ++e) {
                 const int s = e >> 1;
-                if (e == 0)      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
+                if (KB >= 8) {
+                    // K = 256 keeps part of its operands in AGPRs; the copies the compiler makes for an inline-asm MFMA sit right in
+                    // front of it, and the hazard recogniser cannot see into the asm (measured: ~1 % wrong sums in the W-step).
+                    // The builtin is an instruction the compiler knows: it places the wait states itself.
+                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
+                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
+                }
+                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
                 else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
                 else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
                 else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                         const int en = e + D, gn = en / NT, tn = en % NT;
                         a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
                     }
-                    if (!LAST && e < 4 * NPC) {   // 4 * NPC == E2: exactly one per MFMA
+                    if (DB && !LAST && e < 4 * NPC) {   // 4 * NPC == E2: exactly one per MFMA
                         stage_store_one(vn, e, vs_tag);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -284,6 +298,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             if (!LAST) x_park();    // the tile of superchunk sc + 2
             __syncthreads();
+            if (!DB && !LAST) {     // everybody has finished with the one image: replace it
+#pragma unroll
+                for (int w4 = 0; w4 < 4 * NPC; ++w4) stage_store_one(vn, w4, vs_tag);
+                __syncthreads();
+            }
         };
         if (vs_on) for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::true_type{});
         else       for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::false_type{});
@@ -417,11 +436,11 @@ hipError_t launch_split_apply(float *U, const float *partials, const float *vpar
     return hipGetLastError();
 }
 
-template <int KB, int NW, int OCC>
+template <int KB, int NW, int OCC, bool DB = true>
 static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t stream) {
     const int Q = wstep ? a.Mv : a.Nv;   // the column groups beyond hold zero padding only: it stays zero without being touched
     const dim3 grid((unsigned)((Q / 16) * a.nsplit), (unsigned)a.batch), block(64 * NW);
-    const size_t lds = split_step_lds_bytes(a.Kp, NW);
+    const size_t lds = split_step_lds_bytes(a.Kp, NW, DB);
     const bool partial = a.nsplit > 1 || a.force_partial;
     const bool fast = fused_fast_divide() || a.fast_divide;
 #define NMF_LAUNCH_S16(...)                                                                               \
@@ -431,22 +450,22 @@ static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t s
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
     if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 1, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 1, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 1, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 1, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 1, OCC, DB>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 1, OCC, DB>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 1, OCC, DB>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 1, OCC, DB>);
     } else {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 0, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 0, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 0, OCC>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 0, OCC>);
+        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, false, 0, OCC, DB>);
+        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, false, true, 0, OCC, DB>);
+        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, false, 0, OCC, DB>);
+        else NMF_LAUNCH_S16(split_step_kernel_k16<KB, NW, true, true, 0, OCC, DB>);
     }
 #undef NMF_LAUNCH_S16
     return hipGetLastError();
 }
 
-size_t split_step_lds_bytes(int Kp, int nw) { return ((size_t)2 * nw * Kp * kLdv + nw * kXs16Floats) * sizeof(float); }
-bool split_step_supports(int Kp) { return Kp == 32 || Kp == 64 || Kp == 128; }
+size_t split_step_lds_bytes(int Kp, int nw, bool db) { return ((size_t)(db ? 2 : 1) * nw * Kp * kLdv + nw * kXs16Floats) * sizeof(float); }
+bool split_step_supports(int Kp) { return Kp == 32 || Kp == 64 || Kp == 128 || Kp == 256; }
 
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream) {
     const int nw = wstep ? a.nw_w : a.nw_h;
@@ -459,7 +478,8 @@ hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream)
     switch (a.Kp) {
         case 32:  return launch_split_k16<1, 4, 2>(a, wstep, stream);
         case 64:  return nw == 8 ? launch_split_k16<2, 8, 2>(a, wstep, stream) : launch_split_k16<2, 4, 2>(a, wstep, stream);
-        case 128: return launch_split_k16<4, 4, 1>(a, wstep, stream);
+        case 128: return a.single_image ? launch_split_k16<4, 4, 2, false>(a, wstep, stream) : launch_split_k16<4, 4, 1>(a, wstep, stream);
+        case 256: return launch_split_k16<8, 4, 1, false>(a, wstep, stream);
         default:  return hipErrorInvalidValue;
     }
 }

@@ -15,7 +15,7 @@ def _relF(oracle, a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 96, 32), (100, 70, 17), (257, 130, 64), (33, 1, 1), (1, 33, 5), (1, 1, 1), (300, 1000, 100), (129, 257, 128), (128, 128, 65),
-                                   (60, 70000, 16), (70000, 60, 40), (5000, 7, 128)])
+                                   (60, 70000, 16), (70000, 60, 40), (5000, 7, 128), (200, 300, 256), (64, 96, 200), (1000, 520, 129)])
 def test_split_kernel_half_steps(ng, oracle, M, N, K):
     """one update_h then one update_w on ragged and degenerate sizes: the in-stream normalisers (colsum W, rowsum H) and
     the four-wave reduction must reproduce the oracle; the other factor must not be touched"""
@@ -34,9 +34,10 @@ def test_split_kernel_half_steps(ng, oracle, M, N, K):
     s.close()
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)])
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 64), (4096, 350, 128), (512, 3445, 30), (1024, 2048, 256)])
 def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
-    """BASELINE config 2, the reference's gold shape and the paper's shape, 200 iterations (cuda/nmf.cu:10), default options
+    """BASELINE config 2, the reference's gold shape, the paper's shape and a K = 256 shape (single LDS image, builtin MFMAs in
+    product 1: operands partly in AGPRs), 200 iterations (cuda/nmf.cu:10), default options
     (automatic kernel choice = split kernel, hipGraph replay): the north_star gate is 1e-4, measured ~4e-6"""
     X, W, H = oracle.gen_problem(M, N, K, seed=0)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)
@@ -55,7 +56,8 @@ def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
 
 
 def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
-    for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), False),
+    for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), True), ((256, 256, 300), False),
+                            ((4096, 2048, 256), False), ((4096, 1024, 256), True),
                             ((4096, 65536, 64), False), ((4096, 4096, 128), False), ((4096, 2048, 128), True), ((4096, 8192, 64), False),
                             ((512, 65536, 20), True)):
         s = ng.Solver(M, N, K)
@@ -111,7 +113,7 @@ def test_resume_from_downloaded_factors_equals_uninterrupted_run(ng, oracle):
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
 
 
-@pytest.mark.parametrize("M,N,K,B", [(1024, 512, 64, 5), (512, 350, 128, 3)])
+@pytest.mark.parametrize("M,N,K,B", [(1024, 512, 64, 5), (512, 350, 128, 3), (384, 512, 256, 3)])
 def test_batched_pairs_equal_single_solvers_bit_for_bit(ng, oracle, M, N, K, B):
     """B (W, H) pairs per launch (blockIdx.y) against one resident X: every pair must come out exactly as a solver of its
     own would produce it; frozen pairs (set_active) must not move"""

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nmf_gpu_amd as ng
 rng = np.random.default_rng(0)
 shapes = [(4096, 16384, 128), (4096, 8192, 128), (4096, 4096, 128), (4096, 2048, 128), (4096, 1024, 128), (2048, 16384, 128), (1024, 16384, 128),
-          (4096, 16384, 64), (4096, 8192, 64), (4096, 4096, 64), (4096, 2048, 64), (2048, 8192, 64), (1024, 16384, 64), (1024, 65536, 64), (512, 65536, 32), (8192, 4096, 32)]
+          (4096, 16384, 64), (4096, 8192, 64), (4096, 4096, 64), (4096, 2048, 64), (2048, 8192, 64), (1024, 16384, 64), (1024, 65536, 64), (512, 65536, 32), (8192, 4096, 32),
+          (1024, 4096, 256), (4096, 350, 256), (4096, 1024, 256), (2048, 4096, 256), (4096, 4096, 256), (1024, 1024, 200)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 for (M, N, K) in shapes:
