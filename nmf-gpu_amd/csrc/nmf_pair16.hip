@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_pair(FusedArgs a, do
             const float *__restrict__ vb = smem + par * VBUF;
             float *__restrict__ vn = smem + (par ^ 1) * VBUF;
             set_chunk((ch + 1 < c_end) ? ch + 1 : ch);
-            // ---- product 1 over this wave's k range: two interleaved chains (even / odd steps), summed afterwards
+            // ---- product 1 over this wave's k range: two interleaved chains (even / odd steps), summed afterwards.  Builtin MFMAs, not
+            // inline asm: this kernel keeps part of its registers in AGPRs, and a copy the compiler places right in front of an
+            // asm MFMA is a hazard it cannot see (nmf_split16.hip, K = 256); the builtin costs nothing here (137 TFLOP/s either way)
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             float ar[D];
 #pragma unroll
@@ -178,10 +180,10 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_pair(FusedArgs a, do
             constexpr int G = CHECK ? (N1 / 2) / (NLOAD + 1) : N1 / (NLOAD + 1);
 #pragma unroll
             for (int e = 0; e < N1; ++e) {
-                if (e == 0)      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
-                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[1]));
-                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[e]));
-                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[e]));
+                if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[1], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[e], s1);
+                else             s0 = NMF_MFMA16(ar[e % D], ub[e], s0);
                 if (e + D < N1) {
                     const int en = e + D;
                     ar[e % D] = lds_ld(b1 + (64 * (en >> 4) + (en & 15)) * kLdp);

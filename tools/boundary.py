@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.replace("x", ",").split(",")) for a in sys.argv[1:]]
 for (M, N, K) in shapes:
     W = ng.Matrix(rng.random((M, K), dtype=np.float32)); H = ng.Matrix(rng.random((K, N), dtype=np.float32)); X = ng.Matrix(rng.random((M, N), dtype=np.float32))
-    for it, graph in ((1, 1), (200, 1), (200, 1), (200, 1), (200, -1), (200, -1), (200, 0)):
+    for it, graph in ((1, 2), (200, 2), (200, 2), (200, 1), (200, 1), (200, -1), (200, 0)):
         t0 = time.perf_counter()
         r = ng.update_div_ex(W, H, X, max_iter=it, use_graph=graph)
         dt = time.perf_counter() - t0
