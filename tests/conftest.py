@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# update_div shards a large problem over every visible GPU by itself (nmf_opts.n_devices = 0).  The parity tests are about one
+# GPU: on a multi-GPU host they must not turn into multi-GPU runs behind the test's back.  Tests of the multi-device driver ask
+# for their ranks explicitly (n_devices / emulate_shards), which this does not affect.
+os.environ.setdefault("NMF_DEVICES", "1")
 
 
 def pytest_configure(config):
