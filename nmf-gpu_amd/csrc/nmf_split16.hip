@@ -173,15 +173,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
         };
         const int img_off = sub_hi * VBUF + (WSTEP ? 4 * (tid & 7) * kLdv + g : g * kLdv + 4 * (tid & 7));
+        auto vs_add = [&](int w) {   // piece w joins this thread's share of the streamed factor's sums
+            const int qq = w % NST;
+            if (!WSTEP) vs[qq][0] += (st[w][0] + st[w][1]) + (st[w][2] + st[w][3]);
+            else        vs[qq] += st[w];
+        };
         auto stage_store_one = [&](float *__restrict__ img, int w4, auto vs_tag) {   // one ds_write_b32 of piece w4 / 4
             const int w = w4 / 4, cc = w4 % 4, sp = w / NST, qq = w % NST;
             float *__restrict__ vl = img + img_off + SH * sp * VBUF;
             if (!WSTEP) vl[32 * qq * kLdv + cc] = st[w][cc];
             else        vl[(32 * qq + cc) * kLdv] = st[w][cc];
-            if (decltype(vs_tag)::value && cc == 3) {   // the piece is complete: add it to this thread's share of the streamed factor's sums
-                if (!WSTEP) vs[qq][0] += (st[w][0] + st[w][1]) + (st[w][2] + st[w][3]);
-                else        vs[qq] += st[w];
-            }
+            if (decltype(vs_tag)::value && cc == 3) vs_add(w);   // the piece is complete
         };
         auto x_park = [&]() {    // xg -> patch
             float *w = xt + xw_off;
@@ -205,20 +207,31 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         };
 
         const int sc_last = sc_end - 1;
-        set_v(sc_begin);
-#pragma unroll
-        for (int w = 0; w < NPC; ++w) stage_load_one(w);
+        // Prologue: every global load of the first superchunk and both leading X tiles is issued before the first wait, so the
+        // kernel pays ONE first-touch round trip (the factor was written by the previous launch, on other XCDs), not two
+        f32x4 xg0[2];
         set_x(sc_begin);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) x_load_one(i);
-        x_park();
+        for (int i = 0; i < 2; ++i) {   // the first tile into registers of its own: no copy, hence no wait, before the next loads
+            global_bytes base = (global_bytes)(xcur + (size_t)i * (size_t)xstep);
+            asm volatile("" : "+s"(base));
+            xg0[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
+        }
         set_x(sc_begin + 1 < sc_end ? sc_begin + 1 : sc_last);
 #pragma unroll
         for (int i = 0; i < 2; ++i) x_load_one(i);
+        set_v(sc_begin);
 #pragma unroll
-        for (int w4 = 0; w4 < 4 * NPC; ++w4) stage_store_one(smem, w4, std::true_type{});
+        for (int w = 0; w < NPC; ++w) stage_load_one(w);
+        {
+            float *w = xt + xw_off;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(w + (WSTEP ? 16 * i * 20 : 8 * i * kXtLd)) = xg0[i];
+        }
         x_fetch();
         x_park();
+#pragma unroll
+        for (int w4 = 0; w4 < 4 * NPC; ++w4) stage_store_one(smem, w4, std::true_type{});
         __syncthreads();
 
         // one superchunk; LAST: nothing left to stage (the peeled final iteration); VS: this workgroup's sums are needed
@@ -227,6 +240,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             const int rel = sc - sc_begin, par = rel & 1;
             const float *__restrict__ vb = smem + (DB ? par * IMG : 0) + wave * VBUF;
             float *__restrict__ vn = smem + (DB ? (par ^ 1) * IMG : 0);
+            // The sums of the image staged behind the previous iteration's product 2 are taken here, ahead of the MFMA chain: a
+            // VALU add costs ~4 cycles while nothing else is in flight and ~10 between two f32 MFMAs (stamps: 340 cycles per
+            // superchunk in product 2); the registers still hold the pieces until this iteration's loads overwrite them.  Same
+            // pieces in the same order as before: the sums are bit-identical.
+            if (DB && decltype(vs_tag)::value && rel > 0) {
+#pragma unroll
+                for (int w = 0; w < NPC; ++w) vs_add(w);
+            }
             if (!LAST) { set_v(sc + 1); set_x(sc + 2 < sc_end ? sc + 2 : sc_last); }
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                         a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
                     }
                     if (DB && !LAST && e < 4 * NPC) {   // 4 * NPC == E2: exactly one per MFMA
-                        stage_store_one(vn, e, vs_tag);
+                        stage_store_one(vn, e, std::false_type{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -304,9 +325,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 __syncthreads();
             }
         };
-        if (vs_on) for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::true_type{});
-        else       for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::false_type{});
-        body(sc_last, std::true_type{}, std::false_type{});
+        if (vs_on) { for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::true_type{}); body(sc_last, std::true_type{}, std::true_type{}); }
+        else       { for (int sc = sc_begin; sc < sc_last; ++sc) body(sc, std::false_type{}, std::false_type{}); body(sc_last, std::true_type{}, std::false_type{}); }
     }
 
     // ---- the four waves' accumulators -> one (fixed order), the streamed factor's sums -> K normalisers
