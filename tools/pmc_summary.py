@@ -26,7 +26,7 @@ for k in sorted(ks):
 print()
 for k in sorted(ks):
     c = val[k]
-    if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "fused_step" not in k:
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "step_kernel" not in k:
         continue
     g, w = mean(c["GRBM_GUI_ACTIVE"]) / 8, mean(c["SQ_WAVE_CYCLES"])     # GRBM_GUI_ACTIVE is summed over the 8 XCDs
     ms = mean(dur[k])
@@ -38,7 +38,7 @@ for k in sorted(ks):
 print()
 for k in sorted(ks):
     c = val[k]
-    if "SQ_INSTS_MFMA" not in c or "fused_step" not in k:
+    if "SQ_INSTS_MFMA" not in c or "step_kernel" not in k:
         continue
     mf, va = mean(c["SQ_INSTS_MFMA"]), mean(c["SQ_INSTS_VALU"])
     print(f"* `{k.split('(')[0]}`: MFMA {mf:.3e}, VALU incl. MFMA {va:.3e} (non-MFMA VALU per MFMA: {(va - mf) / mf:.2f}), LDS {mean(c['SQ_INSTS_LDS']):.3e},"
