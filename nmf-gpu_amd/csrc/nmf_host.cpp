@@ -120,6 +120,7 @@ struct nmf_solver {
     bool own_stream = false;
     nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
     bool external_reduce = false;  // sharded, caller reduces the partial buffer
+    bool comm_warm = false;        // one eager all-reduce has run on this communicator (before any capture)
     // device state
     float *W = nullptr, *H = nullptr, *X = nullptr;
     float *normW = nullptr, *normH = nullptr, *rowpart = nullptr;
@@ -795,6 +796,14 @@ static int capture_graph(nmf_solver *s, int iterations, hipGraph_t *graph, hipGr
 static int ensure_level(nmf_solver *s, int li) {
     nmf_solver::Level &l = s->level[li];
     if (l.ready) return NMF_OK;
+    if (s->comm && !s->comm_warm) {
+        // RCCL sets up its transports (buffers, IPC handles, proxy connections) lazily, at the first collective of a communicator;
+        // none of that may happen while a stream is capturing.  One eager all-reduce of the (scratch) partial buffer first: every
+        // rank reaches this point together, the operand is overwritten by the next W-step before anything reads it.
+        NMFCHK(nmf_comm_allreduce_f32(s->comm, s->psum, (size_t)s->Mp * s->Kp + (size_t)s->Kp, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->comm_warm = true;
+    }
     NMFCHK(capture_graph(s, kGraphIters[li], &l.g, &l.e));
     l.ready = true;
     if (li == 2) s->graph_ready = true;
