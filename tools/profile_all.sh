@@ -1,6 +1,6 @@
 cd /root/repo
 export TMPDIR=/tmp
-out=gpurun_out/r02_prof3
+out=gpurun_out/profile_all
 mkdir -p $out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu --timeout 600 > $out/tests.log 2>&1; tail -3 $out/tests.log
 python3 bench.py > $out/bench.json 2> $out/bench.err; cut -c100-420 $out/bench.json
