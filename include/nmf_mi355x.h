@@ -53,7 +53,7 @@ enum {
 
 /* which device path update_div runs */
 enum {
-    NMF_PATH_AUTO = 0,      /* fused when K <= 512, else unfused */
+    NMF_PATH_AUTO = 0,      /* fused when K <= 1024, else unfused */
     NMF_PATH_FUSED = 1,     /* two fused MFMA kernels per iteration, Z never reaches HBM */
     NMF_PATH_UNFUSED = 2    /* op-for-op twin of cuda/nmf.cu:118-176 (16 kernels/iteration) */
 };
