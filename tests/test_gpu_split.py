@@ -342,3 +342,29 @@ def test_wave_pair_kernel_nan_and_out_of_range_inputs(ng, oracle):
     s.close()
     Hr = oracle.update_h(oracle.clamp(W), oracle.clamp(H), oracle.clamp(X))
     assert np.array_equal(np.isnan(H1), np.isnan(Hr)) and np.isnan(H1).sum() == K
+
+
+def test_prepare_captures_without_running_and_describe_names_the_kernel(ng, oracle):
+    """nmf_solver_prepare: the graphs an iterate(n) call replays exist afterwards, nothing has run (factors unchanged), and the
+    prepared solver produces exactly what an unprepared one does; nmf_solver_describe names the kernel family per shape"""
+    M, N, K = 640, 900, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=41)
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.prepare(45)
+    W0, H0 = s.download()
+    assert np.array_equal(W0, oracle.clamp(W)) and np.array_equal(H0, oracle.clamp(H))
+    s.iterate(45)
+    a = s.download()
+    s.close()
+    s = ng.Solver(M, N, K, use_graph=False)
+    s.upload(W, H, X)
+    s.iterate(45)
+    b = s.download()
+    s.close()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for (shape, word) in (((1024, 4096, 64), "split_step_kernel_k16<KB=2>"), ((512, 3445, 30), "split_step_kernel_k16<KB=1>"), ((256, 256, 200), "split_step_kernel_k16<KB=8>"),
+                          ((4096, 65536, 256), "fused_step_kernel_k16<NB=4>"), ((256, 256, 700), "fused_step_kernel_pair<NBH=6>"), ((128, 128, 1100), "unfused")):
+        s = ng.Solver(*shape)
+        assert word in s.describe(), (shape, s.describe())
+        s.close()

@@ -116,3 +116,21 @@ print("sanitized oracle ok")
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_inputs_are_the_reference_generator_extended(oracle):
+    """bench.py draws X -> W -> H from one MT19937 stream, seed 0 -- for rank 0 that must be, value for value, what
+    the oracle's restatement of matrix_export.py:4-7 produces at the same shape (so at 4096 x 350 x 128 the md5-pinned
+    reference inputs); ranks r > 0 get their own X_r, H_r and the SAME W."""
+    import importlib.util, os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    M, N, K = 96, 70, 12
+    X0, W0, H0 = bench.synth_problem(0, M, N, K)
+    Xo, Wo, Ho = oracle.gen_problem(M, N, K, seed=0)
+    assert np.array_equal(X0, Xo) and np.array_equal(W0, Wo) and np.array_equal(H0, Ho)
+    X1, W1, H1 = bench.synth_problem(1, M, N, K)
+    assert np.array_equal(W1, W0) and not np.array_equal(X1, X0) and not np.array_equal(H1, H0)
+    assert X0.flags.f_contiguous and X0.dtype == np.float32
