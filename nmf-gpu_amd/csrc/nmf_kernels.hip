@@ -47,7 +47,12 @@ __global__ __launch_bounds__(256) void apply_partials_kernel(float *__restrict__
     float n_cached = 1.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         float s = P[i];
-        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
+        int sp0 = 1;
+        for (; sp0 + 4 <= nsplit; sp0 += 4) {   // fixed order, four loads in flight
+            const float a0 = P[(size_t)sp0 * count + i], a1 = P[(size_t)(sp0 + 1) * count + i], a2 = P[(size_t)(sp0 + 2) * count + i], a3 = P[(size_t)(sp0 + 3) * count + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; sp0 < nsplit; ++sp0) s += P[(size_t)sp0 * count + i];
         const int k = WSTEP ? (int)(i / (size_t)Mp) : (int)(i % (size_t)Kp);
         if (k != k_cached) {
             k_cached = k;
@@ -100,8 +105,16 @@ __global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict_
     const size_t count = (size_t)Mp * Kp, col = (size_t)k * Mp;
     float acc = 0.f;
     for (int i = threadIdx.x; i < Mp; i += 1024) {
-        float s = P[col + i];
-        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + col + i];
+        // slabs summed in the fixed order 0, 1, 2, ... with four loads in flight: 128-256 workgroups have nothing else to hide an
+        // L2 round trip behind, and eight of them in a row were the whole 12.7 us of this kernel
+        const float *__restrict__ p = P + col + i;
+        float s = p[0];
+        int sp = 1;
+        for (; sp + 4 <= nsplit; sp += 4) {
+            const float a0 = p[(size_t)sp * count], a1 = p[(size_t)(sp + 1) * count], a2 = p[(size_t)(sp + 2) * count], a3 = p[(size_t)(sp + 3) * count];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; sp < nsplit; ++sp) s += p[(size_t)sp * count];
         const float w = __fmul_rn(W[col + i], s / n);   // _rn: the product that is stored is the one that is summed (no fma contraction)
         W[col + i] = w;
         acc = __fadd_rn(acc, w);
@@ -120,7 +133,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ o
                                                            const float *__restrict__ vsum_part, int Kp) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         float s = P[i];
-        for (int sp = 1; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
+        int sp = 1;
+        for (; sp + 4 <= nsplit; sp += 4) {   // fixed order, four loads in flight
+            const float a0 = P[(size_t)sp * count + i], a1 = P[(size_t)(sp + 1) * count + i], a2 = P[(size_t)(sp + 2) * count + i], a3 = P[(size_t)(sp + 3) * count + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; sp < nsplit; ++sp) s += P[(size_t)sp * count + i];
         out[i] = s;
     }
     if (vsum_part) {
