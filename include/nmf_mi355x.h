@@ -121,7 +121,8 @@ typedef struct {
                              * each device's hipGraph; one host thread per device, all inside the call).  0 = automatic: every visible
                              * device when the problem is large enough to amortise the all-reduce (nmf_worth_sharding; the
                              * environment variable NMF_DEVICES=<n>|all overrides), else one; 1 = one; n > 1 = exactly n */
-    const int *devices;     /* optional list of n_devices HIP ordinals; NULL = device, device + 1, ... (device < 0: from 0) */
+    const int *devices;     /* optional list of n_devices HIP ordinals; NULL = device, device + 1, ... (device < 0: from 0).  With
+                             * n_devices = 1 an explicit list still takes the multi-device driver (one thread, one RCCL rank) */
     int   emulate_shards;   /* G > 1: run the multi-device driver with G ranks on ONE device, the all-reduce replaced by a
                              * device-side sum in rank order (for one-GPU test boxes; at most 8) */
 } nmf_opts;

@@ -273,6 +273,11 @@ def _make_opts(**kw) -> _opts:
     for k, v in kw.items():
         if v is None:
             continue
+        if k == "devices":      # a Python list of HIP ordinals; the array must outlive the call: kept on the struct
+            arr = (C.c_int * len(v))(*[int(d) for d in v])
+            o._devices_keepalive = arr
+            o.devices = C.cast(arr, C.POINTER(C.c_int))
+            continue
         if not hasattr(o, k):
             raise TypeError(f"unknown option {k}")
         setattr(o, k, v)

@@ -1129,6 +1129,10 @@ static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, con
         return NMF_OK;
     }
     int want = o.n_devices;
+    if (want == 1 && o.devices && host_data && !o.comm && !o.stream) {   // an explicit one-entry device list: the multi-device driver with
+        devices.push_back(o.devices[0]);                                   // a single RCCL rank (what a one-GPU box can run of it)
+        return NMF_OK;
+    }
     if (want == 1 || want < 0) return NMF_OK;
     if (o.comm || o.stream || !host_data) {
         if (want > 1) { set_err("n_devices > 1 needs host matrices and no caller stream or communicator"); return NMF_ERR_ARG; }
@@ -1167,7 +1171,7 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
         std::vector<int> devices;
         bool emulate = false, automatic = false;
         NMFCHK(plan_devices(o, W, H, X, M, N, K, devices, emulate, automatic));
-        if (devices.size() > 1) {
+        if (!devices.empty()) {
             const int st = nmf_update_div_multi(W, H, X, o, devices.data(), (int)devices.size(), emulate, res);
             if (!(st == NMF_ERR_COMM && automatic)) return st;
             fprintf(stderr, "nmf: no RCCL communicator over %d devices; running on one GPU\n", (int)devices.size());

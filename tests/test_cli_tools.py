@@ -160,3 +160,18 @@ def test_multi_device_requests_that_cannot_be_met_are_refused(ng):
     assert r["n_shards"] == 1 and r["w_replicas_identical"] == 1
     r = ng.update_div_ex(W, H, X, max_iter=3, emulate_shards=2, converge_thresh=1e-30, iter_check=1)
     assert r["n_shards"] == 2 and r["iterations"] == 3 and len(r["kl"]) == 4 and r["kl"][0] > r["kl"][-1]
+
+
+@pytest.mark.gpu
+def test_multi_device_driver_over_real_rccl_with_the_one_device_of_the_box(ng, oracle):
+    """update_div_ex(n_devices=1, devices=[0]): the in-library driver end to end over RCCL itself -- ncclCommInitAll, the rank's
+    host thread, the eager warm-up all-reduce, the all-reduce captured in the rank's hipGraphs, KL checks all-reduced, H gathered --
+    with the single rank a one-GPU box allows (N > 1 ranks over xGMI remain unmeasured)"""
+    import numpy as np
+    M, N, K = 1024, 8192, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=23)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=40, n_devices=1, devices=[0], converge_thresh=1e-30, iter_check=20, use_graph=1)
+    assert r["n_shards"] == 1 and r["w_replicas_identical"] == 1 and r["iterations"] == 40 and len(r["kl"]) == 3
+    Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 40, 20)
+    assert oracle.relF(Wm.mat, Wr) < 1e-5 and oracle.relF(Hm.mat, Hr) < 1e-5 and np.allclose(r["kl"], klr, rtol=2e-5)
