@@ -60,6 +60,7 @@ struct EmuGroup {
     std::condition_variable cv;
     int arrived = 0;
     unsigned long generation = 0;
+    bool aborted = false;            // a rank has failed: nobody waits for it any more
     const void *buf[kMaxEmu] = {};
     hipEvent_t ev1[kMaxEmu] = {}, ev2[kMaxEmu] = {};
     void *tmp[kMaxEmu] = {};
@@ -71,11 +72,18 @@ struct EmuGroup {
             if (tmp[i]) (void)hipFree(tmp[i]);
         }
     }
-    void rendezvous() {
+    bool rendezvous() {              // false: the group was aborted
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const unsigned long gen = generation;
         if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else cv.wait(lk, [&] { return generation != gen || aborted; });
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -161,6 +169,15 @@ int nmf_comm_create_emulated(nmf_comm **out, int n) {
     return NMF_OK;
 }
 bool nmf_comm_capturable(const nmf_comm *c) { return c && !c->emu; }
+// a rank that has failed outside a collective tells the group, so that the others do not wait for it for ever
+void nmf_comm_abort(nmf_comm *c) {
+    if (!c) return;
+    if (c->emu) { c->emu->abort(); return; }
+    if (c->comm && g_api.ok) {
+        auto fn = (decltype(&ncclCommAbort))dlsym(g_api.handle, "ncclCommAbort");
+        if (fn) { (void)fn(c->comm); c->comm = nullptr; }
+    }
+}
 
 template <typename T>
 static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) {
@@ -175,7 +192,7 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
     }
     g.buf[r] = buf;
     if (hipEventRecord(g.ev1[r], stream) != hipSuccess) return NMF_ERR_HIP;
-    g.rendezvous();                                    // every operand is enqueued and published
+    if (!g.rendezvous()) return NMF_ERR_COMM;          // every operand is enqueued and published
     EmuPtrs ptrs;
     for (int h = 0; h < n; ++h) {
         ptrs.p[h] = g.buf[h];
@@ -185,7 +202,7 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(emu_sum_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (T *)g.tmp[r], count);
     if (hipEventRecord(g.ev2[r], stream) != hipSuccess) return NMF_ERR_HIP;
-    g.rendezvous();                                    // every rank has read every operand ...
+    if (!g.rendezvous()) return NMF_ERR_COMM;          // every rank has read every operand ...
     for (int h = 0; h < n; ++h)
         if (h != r && hipStreamWaitEvent(stream, g.ev2[h], 0) != hipSuccess) return NMF_ERR_HIP;
     if (hipMemcpyAsync(buf, g.tmp[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return NMF_ERR_HIP;   // ... before any is overwritten

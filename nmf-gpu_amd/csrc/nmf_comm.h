@@ -16,3 +16,6 @@ int nmf_comm_init_all(nmf_comm **comms, int n, const int *devices);
 int nmf_comm_create_emulated(nmf_comm **comms, int n);
 // can the collective be captured into a hipGraph? (RCCL: yes; the emulated group needs its host rendezvous: no)
 bool nmf_comm_capturable(const nmf_comm *c);
+// called by a rank that failed outside a collective: wakes (emulated group) or aborts (RCCL) the communicator so that the other
+// ranks' pending collectives return an error instead of waiting for ever
+void nmf_comm_abort(nmf_comm *c);

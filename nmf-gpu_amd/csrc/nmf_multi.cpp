@@ -101,7 +101,7 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             if (!gate.pass(st == NMF_OK)) { if (s) nmf_solver_destroy(s); if (r.status == NMF_OK) { r.status = NMF_ERR_COMM; snprintf(r.err, sizeof r.err, "rank %d: another rank failed during set-up", g); } return; }
             nmf_result rr;
             st = nmf_solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, og.verbose, &rr);
-            if (st != NMF_OK) { fail(st); nmf_solver_destroy(s); return; }
+            if (st != NMF_OK) { fail(st); nmf_comm_abort(comm[(size_t)g]); nmf_solver_destroy(s); return; }
             const double t1 = now_s();
             r.w_copy.resize((size_t)M * K);
             st = nmf_solver_download(s, r.w_copy.data(), H.mat + (size_t)start[(size_t)g] * K);   // H is gathered at the end
