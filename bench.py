@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--N", type=int, default=65536, help="columns PER GPU")
     ap.add_argument("--K", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--preset", choices=["cfg3", "cfg2", "gold", "paper"], default="cfg3",
+                    help="cfg3 (default, BASELINE config 3: the metric's configuration); cfg2 = 1024 x 4096 x 64 (BASELINE config 2), gold = the "
+                         "reference's own 4096 x 350 x 128 (matrix_export.py:4-7), paper = 512 x 3445 x 30: the same JSON line for the small shapes")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="N>1: all-reduce by in-library RCCL captured inside the per-iteration hipGraph (rccl; auto = rccl, falling "
                          "back to torch if the communicator cannot be set up) or through torch.distributed, eager (torch)")
@@ -117,6 +120,8 @@ def main():
                     help="rehearsal only: take the N>1 code path (process group, GpuShard, all-reduce) even with one rank")
     args = ap.parse_args()
 
+    if args.preset != "cfg3":
+        args.M, args.N, args.K = {"cfg2": (1024, 4096, 64), "gold": (4096, 350, 128), "paper": (512, 3445, 30)}[args.preset]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,7 +264,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.strong_total_N else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
-                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {comm_used})" if sharded else " (BASELINE config 3)"),
+                                   + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {comm_used})" if sharded
+                                      else {"cfg3": " (BASELINE config 3)", "cfg2": " (BASELINE config 2)", "gold": " (the reference's own problem)", "paper": " (the paper's example)"}[args.preset]
+                                      if (M, Nloc, K) in ((4096, 65536, 256), (1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)) else ""),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
                        "hipgraph": (not args.no_graph) and shard is None,
                        "parallelism": f"N-sharded x{world}" if sharded else "single GPU"},
