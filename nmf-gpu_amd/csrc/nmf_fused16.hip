@@ -174,7 +174,16 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
 #pragma unroll
             for (int e = 0; e < E1; ++e) {
                 const int s = e >> 1;
-                if (e == 0)      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
+                if (NB >= 7) {
+                    // K >= 448 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
+                    // in front of it and its hazard recogniser cannot see into the asm (nmf_split16.hip, K = 256, came out ~1 % wrong
+                    // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
+                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
+                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
+                }
+                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
                 else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
                 else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
                 else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
