@@ -368,3 +368,40 @@ def test_prepare_captures_without_running_and_describe_names_the_kernel(ng, orac
         s = ng.Solver(*shape)
         assert word in s.describe(), (shape, s.describe())
         s.close()
+
+
+def test_timers_cli_flags_and_single_pair_freeze_on_the_split_path(ng, oracle, tmp_path):
+    """the README's t[10] (README.md:53) on the split kernel: update_div with timers runs eagerly with a hipEvent pair per piece and
+    fills h_step / w_step / apply; a frozen single pair (set_active on an unbatched solver) does not move; the CLI's
+    --emulate-shards runs the multi-device driver"""
+    import os, subprocess
+    from conftest import ROOT
+    M, N, K = 1024, 4096, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=51)
+    t = [0.0] * 10
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, 30, t, 0)
+    names = dict(zip(ng.T_NAMES, t))
+    assert names["h_step"] > 0 and names["w_step"] > 0 and names["apply"] > 0 and names["total"] >= names["h_step"] + names["w_step"]
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 30, 25)
+    assert _relF(oracle, Wm.mat, Wr) < 1e-5 and _relF(oracle, Hm.mat, Hr) < 1e-5
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(3)
+    a = s.download()
+    s.set_active([False])
+    s.iterate(5)
+    b = s.download()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    s.set_active(None)
+    s.iterate(27)
+    c = s.download()
+    s.close()
+    assert np.array_equal(c[0], Wm.mat) and np.array_equal(c[1], Hm.mat)      # 3 + 27 iterations == the eager timed run of 30
+    cli = os.path.join(ROOT, "nmf-gpu_amd", "nmf")
+    for n, A in (("X", X), ("W", W), ("H", H)):
+        oracle.write_bin(str(tmp_path / f"{n}.bin"), A)
+    r = subprocess.run([cli, "--X", str(tmp_path / "X.bin"), "--W", str(tmp_path / "W.bin"), "--H", str(tmp_path / "H.bin"), "--Wout", str(tmp_path / "Wo.bin"),
+                        "--Hout", str(tmp_path / "Ho.bin"), "--iters", "30", "--emulate-shards", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert _relF(oracle, oracle.read_bin(str(tmp_path / "Wo.bin")), Wr) < 1e-5 and _relF(oracle, oracle.read_bin(str(tmp_path / "Ho.bin")), Hr) < 1e-5
