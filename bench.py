@@ -9,6 +9,9 @@ N = 1: BASELINE config 3, (M, N, K) = (4096, 65536, 256), fp32, W/H/X resident i
 N > 1: weak scaling -- every rank owns 65536 columns of X and H (N = 4 is BASELINE config 4,
        M=4096 N=262144 R=256), W replicated, one all-reduce of [Z*H' ; rowsum(H)] per iteration
        (in-library RCCL captured inside each rank's hipGraph; --comm torch: torch.distributed, eager).
+       --preset cfg4 / cfg5: the two sharded BASELINE configs as STRONG scaling (262144 resp. 131072 columns in all, split
+       over the ranks; on one GPU the whole problem).  The N > 1 line also carries allreduce_ms_per_step / compute_ms_per_step
+       (hipEvent pairs of an eager pass) and the RCCL library actually loaded.
 A "step" is one full iteration (H half-step + W half-step, cuda/nmf.cu:108-109).
 Protocol: W warm-up steps, then `--repeats` (5) timed regions of exactly K steps each, every region
 bracketed by barrier + synchronize and maxed over ranks; `value` / `ms_per_step` are the MEDIAN region, all regions are
@@ -30,7 +33,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU 
 # PMC numbers are NOT measured by this script (counters need rocprofv3 passes of their own): the block below is copied from
 # the committed profile of this command and is reported under "pmc_static" with its source, never mixed into live values.
 PMC_STATIC = {(4096, 65536, 256): {
-    "source": "profiles/r02_pmc_summary.md: rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (not this run)",
+    "source": "profiles/r03_pmc_summary.md: rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (not this run)",
     "hbm_bytes_per_launch": {"H": 1.369e9, "W": 1.208e9}, "algorithmic_bytes_per_launch": 1.21e9,
     "mfma_busy_frac_of_simd_cycles": {"H": 0.910, "W": 0.917}}}
 
@@ -101,9 +104,10 @@ def main():
     ap.add_argument("--N", type=int, default=65536, help="columns PER GPU")
     ap.add_argument("--K", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
-    ap.add_argument("--preset", choices=["cfg3", "cfg2", "gold", "paper"], default="cfg3",
+    ap.add_argument("--preset", choices=["cfg3", "cfg2", "gold", "paper", "cfg4", "cfg5"], default="cfg3",
                     help="cfg3 (default, BASELINE config 3: the metric's configuration); cfg2 = 1024 x 4096 x 64 (BASELINE config 2), gold = the "
-                         "reference's own 4096 x 350 x 128 (matrix_export.py:4-7), paper = 512 x 3445 x 30: the same JSON line for the small shapes")
+                         "reference's own 4096 x 350 x 128 (matrix_export.py:4-7), paper = 512 x 3445 x 30: the same JSON line for the small shapes; "
+                         "cfg4 = 4096 x 262144 x 256 and cfg5 = 8192 x 131072 x 512 (BASELINE configs 4, 5): strong scaling, the columns split over --gpus")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="N>1: all-reduce by in-library RCCL captured inside the per-iteration hipGraph (rccl; auto = rccl, falling "
                          "back to torch if the communicator cannot be set up) or through torch.distributed, eager (torch)")
@@ -120,7 +124,10 @@ def main():
                     help="rehearsal only: take the N>1 code path (process group, GpuShard, all-reduce) even with one rank")
     args = ap.parse_args()
 
-    if args.preset != "cfg3":
+    if args.preset in ("cfg4", "cfg5"):
+        args.M, args.strong_total_N, args.K = {"cfg4": (4096, 262144, 256), "cfg5": (8192, 131072, 512)}[args.preset]
+        args.N = args.strong_total_N
+    elif args.preset != "cfg3":
         args.M, args.N, args.K = {"cfg2": (1024, 4096, 64), "gold": (4096, 350, 128), "paper": (512, 3445, 30)}[args.preset]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,22 +172,34 @@ def main():
     shard = None
     comm_used = args.comm
     if sharded and args.comm in ("auto", "rccl"):
-        ok = 1
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
+        # Every rank runs the same sequence of torch collectives on both the success and the failure path: rank 0 ALWAYS
+        # broadcasts (a zeroed id when it could not make one) and an ok flag is MIN-reduced after each stage, so a rank that
+        # fails early never leaves the others waiting in a different collective.
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+        why = ""
+        uid = torch.zeros(128, dtype=torch.uint8)
+        ok = True
+        if rank == 0:
+            try:
                 uid = torch.frombuffer(bytearray(ng.Comm.unique_id()), dtype=torch.uint8).clone()
-            uid = uid.cuda()
-            dist.broadcast(uid, 0)
-            comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-        except Exception as e:      # no librccl, init failure, ...
-            ok = 0
+            except Exception as e:      # no librccl, wrong major version, ...
+                ok, why = False, str(e)
+        uid = uid.cuda()
+        dist.broadcast(uid, 0)
+        ok = all_ok(ok)
+        if ok:
+            try:
+                comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:      # ncclCommInitRank failure (e.g. two ranks on one device)
+                ok, why = False, str(e)
+            ok = all_ok(ok)
+        if not ok:
             if args.comm == "rccl":
-                raise
-            print(f"bench.py rank {rank}: in-library RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
-        if int(flag.item()) == 0:
+                raise SystemExit(f"bench.py rank {rank}: --comm rccl: the in-library RCCL communicator could not be set up on every rank ({why or 'another rank failed'})")
+            print(f"bench.py rank {rank}: in-library RCCL unavailable ({why or 'another rank failed'}); using torch.distributed", file=sys.stderr)
             if comm is not None:
                 comm.close()
             comm = None
@@ -234,21 +253,40 @@ def main():
         kl0, kl1 = float(kk[0]), float(kk[1])
 
     # dominant kernel: the fused half-step (H- and W-step instantiations, 4*M*Nloc*K flop per launch each).
-    # Its launch duration is measured live with hipEvent pairs around every launch, on the stream it is launched
-    # on, over a second pass of the same `steps` iterations (launched eagerly: events cannot sit inside a graph
-    # replay); rocprofv3 --kernel-trace of this command gives the same averages (profiles/).
+    # An eager pass of the same `steps` iterations after the timed regions brackets every launch with a hipEvent pair on the
+    # stream it is launched on (events cannot sit inside a graph replay).  The event records between launches cost a few
+    # per cent, so the eager figures are reported as measured (`eager_event_*`) and the roofline's ms_per_launch is the
+    # kernel's SHARE of the eager pass applied to the timed region's ms_per_step: the per-launch figures then add up to at
+    # most the step the bench line reports.  rocprofv3 --kernel-trace of this command gives the same averages (profiles/).
+    ms_step = dt / args.steps * 1e3
+    pieces = None
     if shard is None and s.path == ng.PATH_FUSED:
         tp = s.iterate_timed(args.steps)
-        ms_h, ms_w = tp["h_step"] / args.steps * 1e3, tp["w_step"] / args.steps * 1e3
-        how = f"hipEvent pair around each of {args.steps} launches per kernel, eager pass of the same {args.steps} iterations after the timed region"
+        pieces = {k: tp[k] / args.steps * 1e3 for k in ("h_step", "w_step", "sums", "apply", "allreduce")}
+        eager_h, eager_w = pieces["h_step"], pieces["w_step"]
+        how = (f"hipEvent pair around each of {args.steps} launches per kernel in an eager pass of the same {args.steps} iterations after the timed "
+               f"regions; ms_per_launch = that kernel's share of the eager pass x the timed region's ms_per_step")
     else:
         reps = max(3, min(args.steps, 20))
-        ms_h = s.time_piece(ng.api.T_H_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
-        ms_w = s.time_piece(ng.api.T_W_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
+        eager_h = s.time_piece(ng.api.T_H_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
+        eager_w = s.time_piece(ng.api.T_W_STEP, reps) if s.path == ng.PATH_FUSED else float("nan")
         how = f"hipEvents around {reps} back-to-back launches on the solver stream, after the timed region"
+    if pieces is not None and sum(pieces.values()) > 0:
+        scale = min(1.0, ms_step / sum(pieces.values()))
+        ms_h, ms_w = eager_h * scale, eager_w * scale
+    else:
+        ms_h, ms_w = eager_h, eager_w
     ms_k = max(ms_h, ms_w)
     k_flops = 4.0 * M * Nloc * K
     achieved = k_flops / (ms_k * 1e-3) / 1e12
+    if dist is not None and pieces is not None:      # the slowest rank's figures
+        pv = torch.tensor([pieces["allreduce"], pieces["h_step"] + pieces["w_step"] + pieces["sums"] + pieces["apply"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pv, op=dist.ReduceOp.MAX)
+        ar_ms, comp_ms = float(pv[0]), float(pv[1])
+    elif pieces is not None:
+        ar_ms, comp_ms = pieces["allreduce"], pieces["h_step"] + pieces["w_step"] + pieces["sums"] + pieces["apply"]
+    else:
+        ar_ms, comp_ms = None, None
 
     if rank == 0:
         its = args.steps / dt
@@ -265,8 +303,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
                                    + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {comm_used})" if sharded
-                                      else {"cfg3": " (BASELINE config 3)", "cfg2": " (BASELINE config 2)", "gold": " (the reference's own problem)", "paper": " (the paper's example)"}[args.preset]
-                                      if (M, Nloc, K) in ((4096, 65536, 256), (1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)) else ""),
+                                      else {"cfg3": " (BASELINE config 3)", "cfg2": " (BASELINE config 2)", "gold": " (the reference's own problem)", "paper": " (the paper's example)",
+                                            "cfg4": " (BASELINE config 4, whole on one GPU)", "cfg5": " (BASELINE config 5, whole on one GPU)"}[args.preset]
+                                      if (M, Nloc, K) in ((4096, 65536, 256), (1024, 4096, 64), (4096, 350, 128), (512, 3445, 30), (4096, 262144, 256), (8192, 131072, 512)) else ""),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
                        "hipgraph": (not args.no_graph) and shard is None,
                        "parallelism": f"N-sharded x{world}" if sharded else "single GPU"},
@@ -279,8 +318,22 @@ def main():
                          "kernel": "%s (%s-step launch, the slower of the two)" % (s.describe(), "H" if ms_h >= ms_w else "W"),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
+                         "eager_event_ms_h_step": eager_h, "eager_event_ms_w_step": eager_w,
+                         "eager_event_ms_per_piece": pieces,
                          "measured": how},
         }
+        if sharded:
+            # where an N > 1 step goes: the slowest rank's all-reduce and compute time per step in the eager, event-bracketed
+            # pass (in the graph-replayed timed regions the two overlap nothing either: the all-reduce sits between the W-step's
+            # partial product and its apply), and which RCCL the library actually loaded
+            out["allreduce_ms_per_step"] = ar_ms
+            out["compute_ms_per_step"] = comp_ms
+            out["allreduce_bytes"] = 4 * (M * K + K)
+            out["comm"] = comm_used
+            try:
+                out["rccl"] = ng.comm_library_info() if comm_used == "rccl" else f"torch.distributed ({args.dist_backend})"
+            except Exception as e:
+                out["rccl"] = f"unavailable ({e})"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, Ntot, K, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -47,7 +47,7 @@ enum {
     NMF_ERR_HIP = 3,        /* a HIP runtime call or kernel launch failed */
     NMF_ERR_IO = 4,         /* fopen / fread / fwrite failure (cuda/nmf.cu:196-205) */
     NMF_ERR_NOMEM = 5,
-    NMF_ERR_COMM = 6,       /* RCCL failure */
+    NMF_ERR_COMM = 6,       /* RCCL failure, or a collective that ran into its deadline (NMF_COMM_TIMEOUT_S, default 30 s) */
     NMF_ERR_UNSUPPORTED = 7
 };
 
@@ -120,7 +120,11 @@ typedef struct {
                              * X and H are sharded, W is replicated, one RCCL all-reduce of [Z*H' ; rowsum(H)] per iteration inside
                              * each device's hipGraph; one host thread per device, all inside the call).  0 = automatic: every visible
                              * device when the problem is large enough to amortise the all-reduce (nmf_worth_sharding; the
-                             * environment variable NMF_DEVICES=<n>|all overrides), else one; 1 = one; n > 1 = exactly n */
+                             * environment variable NMF_DEVICES=<n>|all overrides) and `device` does not pin one, else one; 1 = one;
+                             * n > 1 = exactly n.  Every wait of a sharded run has a deadline (NMF_COMM_TIMEOUT_S, default 30 s for the
+                             * first collective): a rank that never arrives gets the group aborted and the call NMF_ERR_COMM; under the
+                             * automatic choice the call then runs on one GPU instead (W.mat / H.mat are written only by a run that
+                             * succeeded on every rank).  update_div_restarts: the number of workers the restarts are dealt to */
     const int *devices;     /* optional list of n_devices HIP ordinals; NULL = device, device + 1, ... (device < 0: from 0).  With
                              * n_devices = 1 an explicit list still takes the multi-device driver (one thread, one RCCL rank) */
     int   emulate_shards;   /* G > 1: run the multi-device driver with G ranks on ONE device, the all-reduce replaced by a
@@ -256,6 +260,11 @@ void *nmf_solver_stream(nmf_solver *s);
  * uploaded once, each (W[i], H[i]) pair runs the same update_div loop, the pair with the lowest final KL
  * divergence wins.  All pairs are updated in place; *best receives the winner's index, kl[i] (may be NULL)
  * each pair's final KL.
+ * Several GPUs ("replicas only", below the size where sharding ONE problem pays): restart i runs on worker i % G, one host
+ * thread + one batched solver + one copy of X per worker, no communicator and no collective.  opts->n_devices = G > 1
+ * (optionally with opts->devices, which may name a device more than once) forces G workers; 0 = automatic: every visible
+ * device unless opts->device pins one (NMF_DEVICES=<n>|all overrides); 1 = one device.  Needs X.mat (host).  Every restart
+ * gets the same kernels and split counts wherever it runs: its result is bit-identical to the one-device call's.
  * ------------------------------------------------------------------------------------- */
 int  update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts,
                          int *best, double *kl);
@@ -270,9 +279,18 @@ typedef struct nmf_comm nmf_comm;
 int  nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]);
 int  nmf_comm_init_rank(nmf_comm **c, const unsigned char id[NMF_COMM_ID_BYTES], int rank, int nranks);
 void nmf_comm_destroy(nmf_comm *c);
+/* one line: version and path of the RCCL library actually loaded, and the rccl.h version this library was compiled against
+ * (a different major version is refused at load) */
+int  nmf_comm_library_info(char *buf, int buflen);
 
 /* 1 if sharding an M x N x K problem over n_devices GPUs amortises the per-iteration all-reduce (what n_devices = 0 uses) */
 int  nmf_worth_sharding(int M, int N, int K, int n_devices);
+
+/* diagnostics: with recording on, every launcher of a fused half-step / check kernel notes the demangled name of the
+ * instantiation it launches (thread-local); nmf_debug_last_kernel returns the most recent one ("" before the first).
+ * Used by the tests to hit every instantiation by name; off by default (one relaxed load per launch). */
+int  nmf_debug_record_kernels(int on);     /* returns the previous setting */
+const char *nmf_debug_last_kernel(void);
 
 /* device queries used by bench/tests */
 int  nmf_device_count(void);

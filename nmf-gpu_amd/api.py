@@ -22,7 +22,7 @@ __all__ = [
     "matrix_multiply", "matrix_multiply_AtB", "matrix_multiply_ABt", "element_multiply", "element_divide",
     "row_divide", "col_divide", "set_epsilon", "sum_cols", "sum_rows", "kl_divergence", "diff_norm",
     "Comm", "device_count", "device_name", "lib", "LIB_PATH", "PATH_AUTO", "PATH_FUSED", "PATH_UNFUSED",
-    "T_NAMES", "declared_symbols",
+    "T_NAMES", "declared_symbols", "comm_library_info", "record_kernels", "last_kernel",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -120,7 +120,10 @@ _SIGS = [
     ("nmf_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("nmf_comm_init_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
     ("nmf_comm_destroy", None, [C.c_void_p]),
+    ("nmf_comm_library_info", C.c_int, [C.c_char_p, C.c_int]),
     ("nmf_worth_sharding", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("nmf_debug_record_kernels", C.c_int, [C.c_int]),
+    ("nmf_debug_last_kernel", C.c_char_p, []),
     ("nmf_device_count", C.c_int, []),
     ("nmf_device_name", C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     ("nmf_version", C.c_char_p, []),
@@ -396,6 +399,23 @@ class Comm:
         if self._h:
             lib().nmf_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def comm_library_info() -> str:
+    """version and path of the RCCL actually loaded (loads it), and the rccl.h version the library was built against"""
+    buf = C.create_string_buffer(768)
+    lib().nmf_comm_library_info(buf, 768)
+    return buf.value.decode()
+
+
+def record_kernels(on: bool = True) -> bool:
+    """switch the launchers' kernel-name recording on or off; returns the previous setting"""
+    return bool(lib().nmf_debug_record_kernels(int(on)))
+
+
+def last_kernel() -> str:
+    """demangled name of the fused half-step / check kernel this thread launched last (with recording on)"""
+    return lib().nmf_debug_last_kernel().decode()
 
 
 def _hostptr(a, rows, cols):

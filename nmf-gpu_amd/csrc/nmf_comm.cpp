@@ -5,11 +5,15 @@
 #include "../../include/nmf_mi355x.h"
 
 #include <dlfcn.h>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 // Types, enums and prototypes come from the RCCL header (compile time only: the library itself is dlopen()ed on first use,
@@ -26,11 +30,21 @@ struct Api {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    int version = 0;            // ncclGetVersion of the loaded library
+    char path[400] = "";        // where it was loaded from (dladdr)
     bool ok = false;
 };
 Api g_api;
+std::mutex g_api_mu;
 
+// The function table is typed by <rccl/rccl.h> (NCCL_VERSION_CODE of the ROCm this library was compiled against) while the
+// shared object comes from wherever the process finds "librccl.so.1" -- under PyTorch that is torch's bundled build, not
+// /opt/rocm's.  The entry points used here (all-reduce, init, destroy, abort, 128-byte unique id) have kept their signatures
+// through NCCL 2.x; a different MAJOR version is refused, the loaded version and path are reported (nmf_comm_library_info).
 bool load_api() {
+    std::lock_guard<std::mutex> lock(g_api_mu);
     if (g_api.ok) return true;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
@@ -44,6 +58,17 @@ bool load_api() {
     g_api.CommDestroy = (decltype(&ncclCommDestroy))dlsym(g_api.handle, "ncclCommDestroy");
     g_api.AllReduce = (decltype(&ncclAllReduce))dlsym(g_api.handle, "ncclAllReduce");
     g_api.GetErrorString = (decltype(&ncclGetErrorString))dlsym(g_api.handle, "ncclGetErrorString");
+    g_api.CommAbort = (decltype(&ncclCommAbort))dlsym(g_api.handle, "ncclCommAbort");
+    g_api.GetVersion = (decltype(&ncclGetVersion))dlsym(g_api.handle, "ncclGetVersion");
+    if (g_api.GetVersion) { int v = 0; if (g_api.GetVersion(&v) == ncclSuccess) g_api.version = v; }
+    Dl_info di;
+    if (g_api.AllReduce && dladdr((void *)g_api.AllReduce, &di) && di.dli_fname) snprintf(g_api.path, sizeof g_api.path, "%s", di.dli_fname);
+    const int major = g_api.version >= 10000 ? g_api.version / 10000 : g_api.version / 1000;   // NCCL_VERSION(X,Y,Z): X*10000 + Y*100 + Z since 2.9
+    if (g_api.version && major != NCCL_MAJOR) {
+        fprintf(stderr, "nmf_comm: %s is RCCL/NCCL %d, this library was built against the %d.x interface (rccl.h %d): refusing it\n",
+                g_api.path, g_api.version, NCCL_MAJOR, NCCL_VERSION_CODE);
+        return false;
+    }
     g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce;
     return g_api.ok;
 }
@@ -72,12 +97,16 @@ struct EmuGroup {
             if (tmp[i]) (void)hipFree(tmp[i]);
         }
     }
-    bool rendezvous() {              // false: the group was aborted
+    bool rendezvous(double timeout_s) {   // false: the group was aborted, or a rank did not arrive within the deadline (aborts it)
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
         const unsigned long gen = generation;
         if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen || aborted; });
+        else if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || aborted; })) {
+            fprintf(stderr, "nmf_comm: a rank of the emulated group did not reach its collective within %.1f s; aborting the group\n", timeout_s);
+            aborted = true;
+            cv.notify_all();
+        }
         return !aborted;
     }
     void abort() {
@@ -85,13 +114,36 @@ struct EmuGroup {
         aborted = true;
         cv.notify_all();
     }
+    bool is_aborted() { std::lock_guard<std::mutex> lk(mu); return aborted; }
+};
+
+// The communicators of one ncclCommInitAll call: aborting one means aborting all (see nmf_comm_abort)
+struct RcclGroup {
+    std::mutex mu;
+    std::vector<nmf_comm *> members;
+    std::atomic<bool> aborted{false};
 };
 
 struct nmf_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     std::shared_ptr<EmuGroup> emu;   // set: a same-device emulated group instead of an RCCL communicator
+    std::shared_ptr<RcclGroup> grp;  // set: one of the communicators of an ncclCommInitAll group
+    std::atomic<bool> aborted{false};
+    // fault injection for the tests (NMF_FAULT_ALLREDUCE=<rank>:<call>): that f32 all-reduce call of that rank fails
+    long calls = 0, fail_at = 0;
 };
+
+double nmf_comm_timeout_s() {
+    const char *e = getenv("NMF_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 30.0;
+}
+static void arm_fault(nmf_comm *c) {
+    const char *e = getenv("NMF_FAULT_ALLREDUCE");
+    int r = -1; long at = 0;
+    if (e && sscanf(e, "%d:%ld", &r, &at) == 2 && r == c->rank) c->fail_at = at;
+}
 
 struct EmuPtrs { const void *p[kMaxEmu]; };
 template <typename T>
@@ -132,8 +184,22 @@ extern "C" int nmf_comm_init_rank(nmf_comm **out, const unsigned char id[NMF_COM
 
 extern "C" void nmf_comm_destroy(nmf_comm *c) {
     if (!c) return;
-    if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);
+    if (c->grp) {
+        std::lock_guard<std::mutex> lk(c->grp->mu);
+        for (auto &m : c->grp->members) if (m == c) m = nullptr;
+        if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);   // nullptr after an abort
+        c->comm = nullptr;
+    } else if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);
     delete c;
+}
+
+extern "C" int nmf_comm_library_info(char *buf, int buflen) {
+    if (!buf || buflen <= 0) return NMF_ERR_ARG;
+    if (!load_api()) { snprintf(buf, (size_t)buflen, "RCCL not loadable"); return NMF_ERR_COMM; }
+    const int v = g_api.version;
+    snprintf(buf, (size_t)buflen, "RCCL %d.%d.%d (%s); built against rccl.h %d.%d.%d", v / 10000, (v / 100) % 100, v % 100, g_api.path[0] ? g_api.path : "?",
+             NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+    return NMF_OK;
 }
 
 // ncclCommInitAll: one process drives n devices (devices[i] = HIP ordinal of rank i), one host thread per rank afterwards
@@ -146,9 +212,12 @@ int nmf_comm_init_all(nmf_comm **out, int n, const int *devices) {
         fprintf(stderr, "nmf_comm: ncclCommInitAll failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
         return NMF_ERR_COMM;
     }
+    auto grp = std::make_shared<RcclGroup>();
     for (int i = 0; i < n; ++i) {
         out[i] = new nmf_comm();
-        out[i]->comm = cs[(size_t)i]; out[i]->rank = i; out[i]->nranks = n;
+        out[i]->comm = cs[(size_t)i]; out[i]->rank = i; out[i]->nranks = n; out[i]->grp = grp;
+        grp->members.push_back(out[i]);
+        arm_fault(out[i]);
     }
     return NMF_OK;
 }
@@ -165,17 +234,49 @@ int nmf_comm_create_emulated(nmf_comm **out, int n) {
     for (int i = 0; i < n; ++i) {
         out[i] = new nmf_comm();
         out[i]->rank = i; out[i]->nranks = n; out[i]->emu = g;
+        arm_fault(out[i]);
     }
     return NMF_OK;
 }
 bool nmf_comm_capturable(const nmf_comm *c) { return c && !c->emu; }
-// a rank that has failed outside a collective tells the group, so that the others do not wait for it for ever
+// a rank that has failed outside a collective (or timed out inside one) tells the group, so that nobody waits for ever
 void nmf_comm_abort(nmf_comm *c) {
     if (!c) return;
+    c->aborted = true;
     if (c->emu) { c->emu->abort(); return; }
-    if (c->comm && g_api.ok) {
-        auto fn = (decltype(&ncclCommAbort))dlsym(g_api.handle, "ncclCommAbort");
-        if (fn) { (void)fn(c->comm); c->comm = nullptr; }
+    if (!g_api.ok || !g_api.CommAbort) return;
+    if (c->grp) {   // every communicator of the group: the peers' kernels poll their OWN communicator's abort flag
+        std::lock_guard<std::mutex> lk(c->grp->mu);
+        c->grp->aborted = true;
+        for (nmf_comm *m : c->grp->members)
+            if (m && m->comm) { (void)g_api.CommAbort(m->comm); m->comm = nullptr; m->aborted = true; }
+        return;
+    }
+    if (c->comm) { (void)g_api.CommAbort(c->comm); c->comm = nullptr; }
+}
+bool nmf_comm_aborted(const nmf_comm *c) {
+    if (!c) return false;
+    if (c->aborted) return true;
+    if (c->emu) return c->emu->is_aborted();
+    return c->grp ? c->grp->aborted.load() : false;
+}
+
+int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char *what) {
+    if (!c) return hipStreamSynchronize(stream) == hipSuccess ? NMF_OK : NMF_ERR_HIP;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool expired = false;
+    for (int spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return nmf_comm_aborted(c) ? NMF_ERR_COMM : NMF_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return NMF_ERR_HIP; }
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!expired && (el > timeout_s || nmf_comm_aborted(c))) {
+            if (el > timeout_s) fprintf(stderr, "nmf_comm: rank %d: %s did not complete within %.1f s; aborting the communicator group\n", c->rank, what ? what : "a collective", timeout_s);
+            nmf_comm_abort(c);
+            expired = true;
+        }
+        if (expired && el > timeout_s + 10.0) return NMF_ERR_COMM;   // the aborted collective should have left the stream by now
+        if (spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 
@@ -192,7 +293,7 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
     }
     g.buf[r] = buf;
     if (hipEventRecord(g.ev1[r], stream) != hipSuccess) return NMF_ERR_HIP;
-    if (!g.rendezvous()) return NMF_ERR_COMM;          // every operand is enqueued and published
+    if (!g.rendezvous(nmf_comm_timeout_s())) return NMF_ERR_COMM;          // every operand is enqueued and published
     EmuPtrs ptrs;
     for (int h = 0; h < n; ++h) {
         ptrs.p[h] = g.buf[h];
@@ -202,7 +303,7 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(emu_sum_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (T *)g.tmp[r], count);
     if (hipEventRecord(g.ev2[r], stream) != hipSuccess) return NMF_ERR_HIP;
-    if (!g.rendezvous()) return NMF_ERR_COMM;          // every rank has read every operand ...
+    if (!g.rendezvous(nmf_comm_timeout_s())) return NMF_ERR_COMM;          // every rank has read every operand ...
     for (int h = 0; h < n; ++h)
         if (h != r && hipStreamWaitEvent(stream, g.ev2[h], 0) != hipSuccess) return NMF_ERR_HIP;
     if (hipMemcpyAsync(buf, g.tmp[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return NMF_ERR_HIP;   // ... before any is overwritten
@@ -213,6 +314,11 @@ int nmf_comm_rank(const nmf_comm *c) { return c ? c->rank : 0; }
 int nmf_comm_size(const nmf_comm *c) { return c ? c->nranks : 1; }
 
 static int allreduce(nmf_comm *c, void *buf, size_t count, ncclDataType_t dtype, hipStream_t stream) {
+    if (c && dtype == ncclFloat32 && c->fail_at > 0 && ++c->calls == c->fail_at) {
+        fprintf(stderr, "nmf_comm: rank %d: injected all-reduce failure (NMF_FAULT_ALLREDUCE)\n", c->rank);
+        return NMF_ERR_COMM;
+    }
+    if (c && nmf_comm_aborted(c)) return NMF_ERR_COMM;
     if (c && c->emu) return dtype == ncclFloat32 ? emu_allreduce(c, (float *)buf, count, stream) : emu_allreduce(c, (double *)buf, count, stream);
     if (!c || !c->comm) return NMF_ERR_ARG;
     const ncclResult_t rc = g_api.AllReduce(buf, buf, count, dtype, ncclSum, c->comm, stream);

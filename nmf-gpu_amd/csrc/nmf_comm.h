@@ -16,6 +16,18 @@ int nmf_comm_init_all(nmf_comm **comms, int n, const int *devices);
 int nmf_comm_create_emulated(nmf_comm **comms, int n);
 // can the collective be captured into a hipGraph? (RCCL: yes; the emulated group needs its host rendezvous: no)
 bool nmf_comm_capturable(const nmf_comm *c);
-// called by a rank that failed outside a collective: wakes (emulated group) or aborts (RCCL) the communicator so that the other
-// ranks' pending collectives return an error instead of waiting for ever
+// called by a rank that failed outside a collective, or whose wait ran into its deadline: wakes every waiter of an emulated
+// group; aborts EVERY communicator of an ncclCommInitAll group (RCCL requires all of them to be aborted: a peer inside
+// ncclAllReduce keeps spinning for a rank whose own communicator alone was aborted) and nulls them, so that the pending and
+// later collectives of every rank return NMF_ERR_COMM instead of waiting for ever.  Idempotent, thread-safe.
 void nmf_comm_abort(nmf_comm *c);
+bool nmf_comm_aborted(const nmf_comm *c);
+// deadline (seconds) of nmf_comm_wait and of the emulated group's host rendezvous: NMF_COMM_TIMEOUT_S, default 30
+double nmf_comm_timeout_s();
+// wait for `stream` to drain, polling, for at most `timeout_s`.  On expiry (a rank that never arrived at a collective leaves
+// its peers' all-reduce kernels spinning) or when another rank has aborted the group: abort the group, give the stream a
+// few seconds to drain its now-aborted collective, and return NMF_ERR_COMM.  c == nullptr: plain hipStreamSynchronize.
+int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char *what);
+
+// the calling thread's nmf_last_error() text (rank threads hand their message to the thread that called update_div_ex)
+void nmf_internal_set_error(const char *msg);

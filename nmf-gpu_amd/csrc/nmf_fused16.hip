@@ -330,6 +330,7 @@ static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t s
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
         if (e != hipSuccess) return e;                                                                    \
+        note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
     if (fast) {
@@ -355,6 +356,8 @@ static hipError_t launch_check_k16(const float *W, const float *H, const float *
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, lds);
     if (e != hipSuccess) return e;
+    note_kernel((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, stream);
+
     hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
     return hipGetLastError();
 }
@@ -367,6 +370,8 @@ static hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int 
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>, lds);
     if (e != hipSuccess) return e;
+    note_kernel((const void *)fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>, stream);
+
     hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, (double *)nullptr);
     return hipGetLastError();
 }

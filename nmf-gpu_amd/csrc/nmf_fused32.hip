@@ -529,6 +529,7 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
             hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
             if (e != hipSuccess) return e;                                                                \
         }                                                                                                 \
+        note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
 #define NMF_LAUNCH_FUSED3(...)                                                                            \
@@ -537,6 +538,7 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
             hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                            \
             if (e != hipSuccess) return e;                                                                \
         }                                                                                                 \
+        note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
     if (variant == 1) {
@@ -567,6 +569,8 @@ hipError_t launch_fused_stamp(const FusedArgs &a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.Np + 127) / 128)), block(256);
     const size_t lds = (size_t)2 * 8 * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
     (void)hipFuncSetAttribute((const void *)fused_step_kernel_v3<8, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    note_kernel((const void *)fused_step_kernel_v3<8, false, false, 0, true>, stream);
+
     hipLaunchKernelGGL((fused_step_kernel_v3<8, false, false, 0, true>), grid, block, lds, stream, a, (double *)nullptr);
     return hipGetLastError();
 }
@@ -660,6 +664,8 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
             hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, lds3);
             if (e != hipSuccess) return e;
         }
+        note_kernel((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, stream);
+
         hipLaunchKernelGGL((fused_step_kernel_v3<KT, false, false, 0, false, true>), dim3(check_num_groups(Np, Kp)), dim3(256), lds3, stream, a, part);
         return hipGetLastError();
     }
@@ -668,6 +674,8 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
         hipError_t e = ensure_dynamic_lds((const void *)check_kernel<KT>, lds);
         if (e != hipSuccess) return e;
     }
+    note_kernel((const void *)check_kernel<KT>, stream);
+
     hipLaunchKernelGGL((check_kernel<KT>), dim3(check_num_groups(Np, Kp)), dim3(256), lds, stream, W, H, X, Mp, Np, Kp, part);
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 using namespace nmf;
@@ -27,6 +28,7 @@ static void set_err(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *nmf_last_error(void) { return g_err; }
+void nmf_internal_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
 
 #define HIPCHK(expr)                                                                                      \
     do {                                                                                                  \
@@ -149,6 +151,7 @@ struct nmf_solver {
     struct Ev { int which; hipEvent_t a, b; };
     std::vector<Ev> events;
     double t_setup = 0.0;
+    double block_budget_s = 1e9;   // sharded runs: deadline of the next wait (solver_run keeps it at a multiple of what a block has taken so far)
 };
 
 // Every device buffer of a solver comes out of ONE allocation: a drop-in update_div call creates and destroys a solver, and a
@@ -190,19 +193,23 @@ static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
     return ns;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr, int batch = 1);
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr, int batch = 1, int split_batch = 0);
 
 extern "C" int nmf_solver_create(nmf_solver **out, int M, int N, int K, const nmf_opts *opts_in) {
     return nmf_solver_create_batched(out, M, N, K, 1, opts_in);
 }
+static int create_batched(nmf_solver **out, int M, int N, int K, int batch, const nmf_opts *opts_in, int split_batch);
 extern "C" int nmf_solver_create_batched(nmf_solver **out, int M, int N, int K, int batch, const nmf_opts *opts_in) {
+    return create_batched(out, M, N, K, batch, opts_in, 0);
+}
+static int create_batched(nmf_solver **out, int M, int N, int K, int batch, const nmf_opts *opts_in, int split_batch) {
     if (!out || M <= 0 || N <= 0 || K <= 0 || batch < 1 || batch > 65535) { set_err("nmf_solver_create: bad arguments"); return NMF_ERR_ARG; }
     nmf_opts o;
     if (opts_in) o = *opts_in; else nmf_default_opts(&o);
     if (batch > 1 && o.comm) { set_err("nmf_solver_create_batched: batched solvers do not shard"); return NMF_ERR_UNSUPPORTED; }
     if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
     nmf_solver *s = new nmf_solver();
-    const int st = solver_init(s, M, N, K, o, nullptr, batch);
+    const int st = solver_init(s, M, N, K, o, nullptr, batch, split_batch);
     if (st != NMF_OK) {   // release whatever was allocated before the failure
         nmf_solver_destroy(s);
         return st;
@@ -226,19 +233,25 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : (kp == 128 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
-// workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128: one
-// workgroup per CU is the target; a function of the shape alone, so that a batched run equals its sequential twin bit for bit
-static int pick_split(int q_valid, int p_extent, int sc_rows) {
+// workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.  One
+// workgroup per CU is the target for a single pair; a launch that carries `batch` pairs (restarts) already hands out
+// batch x column-groups workgroups, and a workgroup-level split then only multiplies fixed costs (prologue, epilogue, slabs and
+// their apply launch): the split shrinks with the batch and disappears once batch x column-groups fills the chip.  `batch` is
+// the restart count of the whole update_div_restarts call (not of one device's or one chunk's share), so that a restart gets
+// the same split -- hence the same bits -- wherever it runs.
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1) {
     const int tasks = q_valid / 16, nsc = p_extent / sc_rows;
     if (tasks >= 192 || nsc <= 1) return 1;
-    int S = 256 / tasks;             // never more workgroups than CUs: a second round costs more than the shorter loop saves
+    if (batch < 1) batch = 1;
+    const long groups = (long)tasks * batch;
+    int S = groups >= 256 ? 1 : (int)(256 / groups);   // never more workgroups than CUs: a second round costs more than the shorter loop saves
     if (S < 1) S = 1;
     if (S > nsc) S = nsc;
     const int scps = (nsc + S - 1) / S;
     return (nsc + scps - 1) / scps;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch) {
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch, int split_batch) {
     const double t0 = now_s();
     s->M = M; s->N = N; s->K = K;
     int path = o.path;
@@ -285,8 +298,9 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         const bool nw8 = s->Kp == 64 && nwe && nwe[0] == '8';
         s->nw_h = (nw8 && s->Mp % 256 == 0) ? 8 : 4;
         s->nw_w = (nw8 && s->Np % 256 == 0) ? 8 : 4;
-        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h);
-        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w);
+        const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call (pick_split)
+        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb);
+        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb);
         const int nsc_h = s->Mp / (32 * s->nw_h), nsc_w = s->Np / (32 * s->nw_w);
         if (s->ns_h > nsc_h) s->ns_h = nsc_h;
         if (s->ns_w > nsc_w) s->ns_w = nsc_w;
@@ -542,6 +556,15 @@ static int collect_timing(nmf_solver *s, double t[10]) {
     return NMF_OK;
 }
 
+// Sharded solvers never block without a deadline: a peer that has died or stalled leaves this rank's all-reduce kernel
+// spinning.  `budget_s` is what the queued work may legitimately take.
+static int wait_stream(nmf_solver *s, double budget_s, const char *what) {
+    if (!s->comm) { HIPCHK(hipStreamSynchronize(s->stream)); return NMF_OK; }
+    const int st = nmf_comm_wait(s->comm, s->stream, budget_s, what);
+    if (st != NMF_OK) set_err("sharded run: %s did not complete (communicator aborted)", what);
+    return st;
+}
+
 // --------------------------------------------------------------------- half-steps
 static FusedArgs fused_args(nmf_solver *s) {
     FusedArgs a;
@@ -639,7 +662,12 @@ static int enqueue_w_partial(nmf_solver *s) {
         a.nsplit = s->ns_w; a.force_partial = 1;
         if (s->ns_w == 1) { a.partials = s->psum; a.vpart = s->psum + mk; }
         { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_split_step(a, true, st)); }
-        if (s->ns_w > 1) { PieceScope p(s, NMF_T_APPLY); HIPCHK(launch_sum_partials(s->psum, s->partials, s->ns_w, mk, st, s->vpart, s->Kp)); }
+        if (s->ns_w > 1) {
+            // rows of W beyond Mv hold zero padding and get no workgroup: their slab entries are whatever an H-step left in the
+            // shared slab buffer, so the sum writes zeros there instead of reading them
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_sum_partials(s->psum, s->partials, s->ns_w, mk, st, s->vpart, s->Kp, s->Mp, a.Mv));
+        }
         return NMF_OK;
     }
     // rowsum(H) (the tail of the all-reduce operand) comes out of the W-step kernel where it can (FusedArgs::vsum_part)
@@ -800,8 +828,11 @@ static int ensure_level(nmf_solver *s, int li) {
         // RCCL sets up its transports (buffers, IPC handles, proxy connections) lazily, at the first collective of a communicator;
         // none of that may happen while a stream is capturing.  One eager all-reduce of the (scratch) partial buffer first: every
         // rank reaches this point together, the operand is overwritten by the next W-step before anything reads it.
+        // It is also the first time the ranks meet: it waits with a deadline (NMF_COMM_TIMEOUT_S), and a rank that never arrives
+        // gets the whole group aborted and every caller an NMF_ERR_COMM instead of a hang (update_div then falls back to one GPU
+        // when sharding was its own idea).
         NMFCHK(nmf_comm_allreduce_f32(s->comm, s->psum, (size_t)s->Mp * s->Kp + (size_t)s->Kp, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        if (nmf_comm_wait(s->comm, s->stream, nmf_comm_timeout_s(), "the first all-reduce") != NMF_OK) { set_err("the first all-reduce of the sharded run did not complete (communicator aborted)"); return NMF_ERR_COMM; }
         s->comm_warm = true;
     }
     NMFCHK(capture_graph(s, kGraphIters[li], &l.g, &l.e));
@@ -920,7 +951,7 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
         if (s->comm) NMFCHK(nmf_comm_allreduce_f64(s->comm, s->chk_out, 3, st));
     }
     HIPCHK(hipMemcpyAsync(s->chk_host.data(), s->chk_out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    NMFCHK(wait_stream(s, s->block_budget_s, "a convergence check"));
     sums[0] = s->chk_host[0]; sums[1] = s->chk_host[1]; sums[2] = s->chk_host[2];
     return NMF_OK;
 }
@@ -965,37 +996,54 @@ extern "C" int nmf_solver_check(nmf_solver *s, double *kl, double *rel_l1) {
 static int solver_run(nmf_solver *s, float thresh, int max_iter, int iter_check, int verbose, nmf_result *res, bool timed) {
     if (!s || max_iter < 0) return NMF_ERR_ARG;
     if (iter_check <= 0) iter_check = NMF_ITER_CHECK_DEFAULT;
+    // verbose = 2: evaluate the checks but print nothing -- the ranks of a sharded run other than rank 0, which must issue
+    // the same sequence of collectives as rank 0 (every check all-reduces its three sums)
     const bool checks = (thresh > 0.f) || verbose;
+    const bool print = verbose == 1;
     s->timing = timed;
     double prev = 0.0, rl1 = 0.0;
     int nkl = 0;
     if (res) { res->n_kl = 0; res->rel_l1 = 0.0; res->path_used = s->path; }
+    // Sharded: the work is handed to the device in blocks that are waited for with a deadline -- first ONE iteration under the
+    // communicator's time-out (the first collectives: transports are being set up, a dead peer shows here), then blocks of
+    // <= 32 under a generous multiple of what an iteration has been seen to take.
+    const bool sharded = s->comm != nullptr;
+    double per_iter_s = 0.0;
+    s->block_budget_s = sharded ? nmf_comm_timeout_s() : 1e9;
     if (checks) {
         NMFCHK(nmf_solver_check(s, &prev, &rl1));
         if (res && nkl < NMF_MAX_KL) res->kl[nkl] = prev;
         nkl++;
-        if (verbose) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", 0, prev, rl1);
+        if (print) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", 0, prev, rl1);
     }
     int it = 0;
     while (it < max_iter) {
         int n = max_iter - it;
         if (checks) { const int to_check = iter_check - (it % iter_check); if (to_check < n) n = to_check; }
         if (timed && n > 256) n = 256;    // timed runs hold two hipEvents per piece: drain them block by block
+        if (sharded) { const int cap = it == 0 ? 1 : 32; if (n > cap) n = cap; }
+        const double tb = now_s();
         NMFCHK(nmf_solver_iterate(s, n));
         it += n;
+        if (sharded) {
+            NMFCHK(wait_stream(s, s->block_budget_s, it == n ? "the first iteration" : "a block of iterations"));
+            const double per = (now_s() - tb) / n;
+            if (per > per_iter_s) per_iter_s = per;
+            s->block_budget_s = nmf_comm_timeout_s() + 100.0 * 32.0 * per_iter_s;
+        }
         if (timed && s->events.size() > 2048) NMFCHK(collect_timing(s, res ? res->t : nullptr));
         if (checks && (it % iter_check) == 0) {
             double cur = 0.0;
             NMFCHK(nmf_solver_check(s, &cur, &rl1));
             if (res && nkl < NMF_MAX_KL) res->kl[nkl] = cur;
             nkl++;
-            if (verbose) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", it, cur, rl1, (prev - cur) / prev);
+            if (print) printf("iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", it, cur, rl1, (prev - cur) / prev);
             const bool stop = thresh > 0.f && (prev - cur) / prev < (double)thresh;   // README.md:51
             prev = cur;
             if (stop) break;
         }
     }
-    HIPCHK(hipStreamSynchronize(s->stream));
+    NMFCHK(wait_stream(s, s->block_budget_s, "the end of the run"));
     HIPCHK(hipGetLastError());   // the reference never polls launch errors; we do
     if (res) { res->iterations = it; res->n_kl = nkl < NMF_MAX_KL ? nkl : NMF_MAX_KL; res->rel_l1 = rl1; }
     if (timed) NMFCHK(collect_timing(s, res ? res->t : nullptr));
@@ -1115,16 +1163,23 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
 // ------------------------------------------------------------------------------ update_div
 int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const int *devices, int G, bool emulate, nmf_result *res);   // nmf_multi.cpp
 
-// How many ranks, on which devices: nmf_opts.n_devices / devices / emulate_shards, NMF_DEVICES, nmf_worth_sharding
+// How many ranks, on which devices: nmf_opts.n_devices / devices / emulate_shards, NMF_DEVICES, NMF_EMULATE_SHARDS,
+// nmf_worth_sharding.  `automatic` = the caller did not ask for several devices (n_devices = 0 and no emulate_shards): the
+// choice came from the environment or the heuristic, and update_div_ex may fall back to one GPU if the sharded run fails.
 static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, const matrix &X, int M, int N, int K,
                         std::vector<int> &devices, bool &emulate, bool &automatic) {
     devices.clear(); emulate = false; automatic = false;
     const bool host_data = W.mat && H.mat && X.mat;
-    if (o.emulate_shards > 1) {
-        if (o.emulate_shards > 8 || !host_data || o.comm || o.stream || N < o.emulate_shards) { set_err("emulate_shards: needs host matrices, at most 8 ranks, N >= ranks, no caller stream or communicator"); return NMF_ERR_ARG; }
+    int emu = o.emulate_shards;
+    if (emu <= 1 && o.n_devices == 0 && host_data && !o.comm && !o.stream) {   // test boxes: the sharded driver without the caller asking
+        const char *e = getenv("NMF_EMULATE_SHARDS");
+        if (e && atoi(e) > 1 && atoi(e) <= 8 && N >= atoi(e)) { emu = atoi(e); automatic = true; }
+    }
+    if (emu > 1) {
+        if (emu > 8 || !host_data || o.comm || o.stream || N < emu) { set_err("emulate_shards: needs host matrices, at most 8 ranks, N >= ranks, no caller stream or communicator"); return NMF_ERR_ARG; }
         int cur = 0;
         if (o.device >= 0) cur = o.device; else HIPCHK(hipGetDevice(&cur));
-        devices.assign((size_t)o.emulate_shards, cur);
+        devices.assign((size_t)emu, cur);
         emulate = true;
         return NMF_OK;
     }
@@ -1141,9 +1196,14 @@ static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, con
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     if (want == 0) {
+        automatic = true;
+        // a caller that names ONE device (nmf --device 3, update_div_ex(device = 3)) gets that device, as before sharding existed
+        if (o.device >= 0 && !o.devices) return NMF_OK;
         const char *e = getenv("NMF_DEVICES");
         if (e && e[0]) want = (strcmp(e, "all") == 0) ? ndev : atoi(e);
-        else { want = (ndev > 1 && nmf_worth_sharding(M, N, K, ndev)) ? ndev : 1; automatic = true; }
+        else want = (ndev > 1 && nmf_worth_sharding(M, N, K, ndev)) ? ndev : 1;
+        if (want > ndev) want = ndev;
+        if (want > N) want = N;
         if (want <= 1) return NMF_OK;
     }
     const int base = o.devices ? 0 : (o.device >= 0 ? o.device : 0);
@@ -1174,7 +1234,10 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
         if (!devices.empty()) {
             const int st = nmf_update_div_multi(W, H, X, o, devices.data(), (int)devices.size(), emulate, res);
             if (!(st == NMF_ERR_COMM && automatic)) return st;
-            fprintf(stderr, "nmf: no RCCL communicator over %d devices; running on one GPU\n", (int)devices.size());
+            // Sharding was the library's own idea and it failed (no communicator, a rank that never reached the first collective,
+            // a collective that broke mid-run).  nmf_update_div_multi writes W.mat / H.mat only after EVERY rank has succeeded,
+            // so the caller's factors are still the initial ones: run the whole problem on one GPU, in this process.
+            fprintf(stderr, "nmf: the sharded run over %d %s failed (%s); running on one GPU\n", (int)devices.size(), emulate ? "emulated shards" : "devices", nmf_last_error());
             memset(res, 0, sizeof *res);
             res->n_shards = 1; res->w_replicas_identical = 1;
         }
@@ -1219,7 +1282,7 @@ extern "C" int update_div_ex(matrix W, matrix H, matrix X, const nmf_opts *opts_
 // Multi-restart (paper section 3.2): X resident once, every (W,H) pair through the same loop, best final KL wins.
 // Several solvers iterate side by side, each on its own stream, with solver_run's convergence logic applied per lane:
 // the enqueue of a block of iterations is asynchronous, so the lanes' kernels overlap on the device.
-static int run_lanes(std::vector<nmf_solver *> &lane, int n, float thresh, int max_iter, int iter_check, int verbose, int first_index) {
+static int run_lanes(std::vector<nmf_solver *> &lane, int n, float thresh, int max_iter, int iter_check, int verbose, int first_index, const int *gidx = nullptr) {
     if (iter_check <= 0) iter_check = NMF_ITER_CHECK_DEFAULT;
     const bool checks = (thresh > 0.f) || verbose;
     std::vector<double> prev((size_t)n, 0.0);
@@ -1228,7 +1291,7 @@ static int run_lanes(std::vector<nmf_solver *> &lane, int n, float thresh, int m
     if (checks)
         for (int l = 0; l < n; ++l) {
             NMFCHK(nmf_solver_check(lane[l], &prev[l], &rl1));
-            if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", first_index + l, 0, prev[l], rl1);
+            if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", gidx ? gidx[first_index + l] : first_index + l, 0, prev[l], rl1);
         }
     for (int it = 0; it < max_iter;) {
         int nstep = max_iter - it;
@@ -1242,7 +1305,7 @@ static int run_lanes(std::vector<nmf_solver *> &lane, int n, float thresh, int m
                 if (done[l]) continue;
                 double cur = 0.0;
                 NMFCHK(nmf_solver_check(lane[l], &cur, &rl1));
-                if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", first_index + l, it, cur, rl1, (prev[l] - cur) / prev[l]);
+                if (verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", gidx ? gidx[first_index + l] : first_index + l, it, cur, rl1, (prev[l] - cur) / prev[l]);
                 if (thresh > 0.f && (prev[l] - cur) / prev[l] < (double)thresh) done[l] = 1;   // README.md:51
                 prev[l] = cur;
             }
@@ -1266,14 +1329,14 @@ static int auto_lanes(const nmf_solver *s, int n_restarts) {
 // all B pairs (B x the workgroups; X tiles shared through L2), each pair iterating exactly as a sequential update_div on
 // it would -- same kernels, same split counts, hence the same bits -- and freezing at its own convergence check.
 constexpr int kMaxRestartBatch = 64;
-static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl) {
+static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     nmf_opts o = o_in;
     // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
     // batch outlasts its own enqueue by far): 16 restarts x 200 iterations on the gold shape take 67 ms eagerly, 90 ms captured
     if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
     nmf_solver *s = nullptr;
-    NMFCHK(nmf_solver_create_batched(&s, M, N, K, B, &o));
+    NMFCHK(create_batched(&s, M, N, K, B, &o, split_batch));
     int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
     const int iter_check = o.iter_check > 0 ? o.iter_check : NMF_ITER_CHECK_DEFAULT;
     const bool checks = (o.converge_thresh > 0.f) || o.verbose;
@@ -1288,7 +1351,7 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
         if (st == NMF_OK) st = nmf_solver_set_active(s, act.data());
         if (st == NMF_OK && checks) {
             st = nmf_solver_check_all(s, prev.data(), rl1.data());
-            if (o.verbose) for (int b = 0; b < n; ++b) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", base + b, 0, prev[(size_t)b], rl1[(size_t)b]);
+            if (o.verbose) for (int b = 0; b < n; ++b) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", gidx ? gidx[base + b] : base + b, 0, prev[(size_t)b], rl1[(size_t)b]);
         }
         for (int it = 0; st == NMF_OK && it < o.max_iter;) {
             int nstep = o.max_iter - it;
@@ -1304,7 +1367,7 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
                 for (int b = 0; st == NMF_OK && b < n; ++b) {
                     if (!act[(size_t)b]) continue;
                     const double p = prev[(size_t)b], c = cur[(size_t)b];
-                    if (o.verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", base + b, it, c, rl1[(size_t)b], (p - c) / p);
+                    if (o.verbose) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e  change %.3e\n", gidx ? gidx[base + b] : base + b, it, c, rl1[(size_t)b], (p - c) / p);
                     if (o.converge_thresh > 0.f && (p - c) / p < (double)o.converge_thresh) { act[(size_t)b] = 0; changed = true; }   // README.md:51
                     prev[(size_t)b] = c;
                 }
@@ -1324,20 +1387,13 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
     return st;
 }
 
-extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts_in, int *best, double *kl) {
-    if (!W || !H || n_restarts < 1 || (!X.mat && !X.mat_d)) { set_err("update_div_restarts: bad arguments"); return NMF_ERR_ARG; }
-    nmf_opts o;
-    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
-    const int M = X.dim[0], N = X.dim[1], K = W[0].dim[1];
-    for (int i = 0; i < n_restarts; ++i) {
-        if (!W[i].mat || !H[i].mat) { set_err("update_div_restarts: pair %d has no host data", i); return NMF_ERR_ARG; }
-        if (W[i].dim[0] != M || W[i].dim[1] != K || H[i].dim[0] != K || H[i].dim[1] != N) {
-            set_err("update_div_restarts: pair %d: dimensions do not agree", i);
-            return NMF_ERR_SHAPE;
-        }
-    }
+// all restarts of `W`, `H` on ONE device (o.device, or the current one); split_batch: restart count of the whole call
+static int restarts_one_device(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
+    if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
     // restart_lanes > 0 asks for the stream-lane mechanism explicitly (the shapes the split kernel does not take use it anyway)
-    if (n_restarts > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o)) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl);
+    if (n_restarts > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o)) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch, gidx);
+    if (n_restarts == 1 && split_batch > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o))   // this device's share of a batched call
+        return restarts_batched(W, H, 1, X, o, M, N, K, best, kl, split_batch, gidx);
     std::vector<nmf_solver *> lane;
     nmf_solver *s0 = nullptr;
     NMFCHK(nmf_solver_create(&s0, M, N, K, &o));
@@ -1358,7 +1414,7 @@ extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_resta
     for (int base = 0; st == NMF_OK && base < n_restarts; base += lanes) {
         const int n = (n_restarts - base < lanes) ? (n_restarts - base) : lanes;
         for (int l = 0; st == NMF_OK && l < n; ++l) st = nmf_solver_upload(lane[l], W[base + l].mat, H[base + l].mat, nullptr);
-        if (st == NMF_OK) st = run_lanes(lane, n, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, base);
+        if (st == NMF_OK) st = run_lanes(lane, n, o.converge_thresh, o.max_iter, o.iter_check, o.verbose, base, gidx);
         for (int l = 0; st == NMF_OK && l < n; ++l) {
             double v = 0.0;
             st = nmf_solver_check(lane[l], &v, nullptr);
@@ -1372,6 +1428,83 @@ extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_resta
     for (size_t l = lane.size(); l-- > 0;) nmf_solver_destroy(lane[l]);   // s0 (the owner of X) last
     if (st == NMF_OK && best) *best = best_i;
     return st;
+}
+
+// Which devices share the restarts ("replicas only": SURVEY 8e / 8f4 -- below the size where sharding one problem pays, a node's
+// GPUs are used by giving each its own restarts; no communicator, no collective, nothing to wait for but the threads).
+// nmf_opts.n_devices = n > 1 (with an optional `devices` list, which may name a device more than once: each entry is a worker
+// with its own solver and stream) forces; 0 = automatic: every visible device unless the caller pinned one (device >= 0) or
+// NMF_DEVICES=<n>|all says otherwise; 1 = the one device.
+static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x, std::vector<int> &devices) {
+    devices.clear();
+    if (o.comm || o.stream || !host_x || n_restarts < 2) return;
+    int want = o.n_devices;
+    if (want == 1 || want < 0) return;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    if (want == 0) {
+        if (o.device >= 0 && !o.devices) return;
+        const char *e = getenv("NMF_DEVICES");
+        want = (e && e[0]) ? ((strcmp(e, "all") == 0) ? ndev : atoi(e)) : ndev;
+        if (want > ndev) want = ndev;
+    }
+    if (want > n_restarts) want = n_restarts;
+    if (want <= 1) return;
+    const int base = o.devices ? 0 : (o.device >= 0 ? o.device : 0);
+    for (int g = 0; g < want; ++g) {
+        const int d = o.devices ? o.devices[g] : base + g;
+        if (d < 0 || d >= ndev) { devices.clear(); return; }
+        devices.push_back(d);
+    }
+}
+
+extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts_in, int *best, double *kl) {
+    if (!W || !H || n_restarts < 1 || (!X.mat && !X.mat_d)) { set_err("update_div_restarts: bad arguments"); return NMF_ERR_ARG; }
+    nmf_opts o;
+    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    const int M = X.dim[0], N = X.dim[1], K = W[0].dim[1];
+    for (int i = 0; i < n_restarts; ++i) {
+        if (!W[i].mat || !H[i].mat) { set_err("update_div_restarts: pair %d has no host data", i); return NMF_ERR_ARG; }
+        if (W[i].dim[0] != M || W[i].dim[1] != K || H[i].dim[0] != K || H[i].dim[1] != N) {
+            set_err("update_div_restarts: pair %d: dimensions do not agree", i);
+            return NMF_ERR_SHAPE;
+        }
+    }
+    if (o.n_devices > 1 && (o.comm || o.stream || !X.mat)) { set_err("update_div_restarts: n_devices > 1 needs a host X and no caller stream or communicator"); return NMF_ERR_ARG; }
+    const int split_batch = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
+    std::vector<int> devices;
+    plan_restart_devices(o, n_restarts, X.mat != nullptr, devices);
+    if (o.n_devices > 1 && devices.empty() && n_restarts > 1) { set_err("update_div_restarts: n_devices = %d: not that many devices visible", o.n_devices); return NMF_ERR_ARG; }
+    if (devices.empty()) return restarts_one_device(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch);
+
+    // Restart i goes to worker i % G: one host thread, one (batched) solver, one upload of X per worker.  Every restart runs the
+    // same kernels with the same split counts as in a one-device call (split_batch), so its result has the same bits.
+    const int G = (int)devices.size();
+    struct Worker { std::vector<matrix> W, H; std::vector<int> idx; std::vector<double> kl; int status = NMF_OK; char err[512] = ""; };
+    std::vector<Worker> wk((size_t)G);
+    for (int i = 0; i < n_restarts; ++i) { Worker &w = wk[(size_t)(i % G)]; w.W.push_back(W[i]); w.H.push_back(H[i]); w.idx.push_back(i); }
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+        th.emplace_back([&, g]() {
+            Worker &w = wk[(size_t)g];
+            nmf_opts og = o;
+            og.device = devices[(size_t)g]; og.n_devices = 1; og.devices = nullptr; og.emulate_shards = 0;
+            w.kl.assign(w.idx.size(), 0.0);
+            int b = -1;
+            w.status = restarts_one_device(w.W.data(), w.H.data(), (int)w.idx.size(), X, og, M, N, K, &b, w.kl.data(), split_batch, w.idx.data());
+            if (w.status != NMF_OK) snprintf(w.err, sizeof w.err, "device %d: %s", devices[(size_t)g], nmf_last_error());
+        });
+    for (auto &t : th) t.join();
+    int best_i = -1;
+    double best_kl = 0.0;
+    for (int g = 0; g < G; ++g) if (wk[(size_t)g].status != NMF_OK) { set_err("%s", wk[(size_t)g].err); return wk[(size_t)g].status; }
+    for (int i = 0; i < n_restarts; ++i) {   // in restart order: the lowest index wins a tie, as on one device
+        const double v = wk[(size_t)(i % G)].kl[(size_t)(i / G)];
+        if (kl) kl[i] = v;
+        if (best_i < 0 || v < best_kl) { best_i = i; best_kl = v; }
+    }
+    if (best) *best = best_i;
+    return NMF_OK;
 }
 
 // README.md:40-46.  void + exit on error like the reference (error-check.hpp:12-17).

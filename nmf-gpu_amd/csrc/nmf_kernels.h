@@ -14,6 +14,11 @@ constexpr int kMaxFusedK = 1024;               // fused path: K <= 1024 (32x32x2
 
 inline int pad32(int v) { return (v + 31) & ~31; }
 
+// Which instantiation did a launcher pick?  With recording on (nmf_debug_record_kernels) every launcher of a fused kernel notes
+// the demangled name of the kernel it launches (hipKernelNameRefByPtr of the very function pointer handed to the launch) in a
+// thread-local string: tests hit every instantiation BY NAME (tests/test_gpu_instantiations.py).  Off: one relaxed load.
+void note_kernel(const void *host_fn, hipStream_t stream);
+
 // ---------------------------------------------------------------- fused half-steps
 // One half-step of update_div on zero-padded device buffers (all dims multiples of 32).
 //   H-step (wstep=false): streamed factor V = W (Mp x Kp), owned factor U = H (Kp x Np).
@@ -96,8 +101,10 @@ hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, co
                                  int Mp, int Kp, float *norm_out, hipStream_t stream);
 // psum = sum_s partials[s]   (sharded W-step: operand of the all-reduce)
 // vsum_part != nullptr: also psum[count + k] = sum_s vsum_part[s][k], k < Kp (the unclamped row sums of H behind the slab sum)
+// q_valid > 0 (with Mp, the slabs' leading dimension): rows >= q_valid of every column were written by no workgroup (zero
+// padding) and may hold stale values of another use of the slab buffer: psum gets 0 there without reading them
 hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream,
-                               const float *vsum_part = nullptr, int Kp = 0);
+                               const float *vsum_part = nullptr, int Kp = 0, int Mp = 0, int q_valid = 0);
 // W[m,k] *= psum[m,k] / max(hsum[k], EPS)
 hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp, int Kp, hipStream_t stream);
 

@@ -5,6 +5,26 @@
 // cuda/matrix.cu:127-250 (elementwise operators), cuda/matrix.cu:505-735 (reductions).
 #include "nmf_device.h"
 
+#include <atomic>
+#include <cxxabi.h>
+#include <string>
+
+namespace nmf {
+static std::atomic<int> g_record_kernels{0};
+static thread_local std::string g_last_kernel;
+void note_kernel(const void *host_fn, hipStream_t stream) {
+    if (!g_record_kernels.load(std::memory_order_relaxed)) return;
+    const char *m = hipKernelNameRefByPtr(host_fn, stream);
+    if (!m) { g_last_kernel = "?"; return; }
+    int st = 0;
+    char *d = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+    g_last_kernel = (st == 0 && d) ? d : m;
+    free(d);
+}
+}  // namespace nmf
+extern "C" __attribute__((visibility("default"))) int nmf_debug_record_kernels(int on) { return nmf::g_record_kernels.exchange(on ? 1 : 0); }
+extern "C" __attribute__((visibility("default"))) const char *nmf_debug_last_kernel(void) { return nmf::g_last_kernel.c_str(); }
+
 namespace nmf {
 
 // which kernel family serves a padded K: the 16-column kernel for K = 64/128/256 (two workgroups per CU) and for
@@ -130,8 +150,9 @@ hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, co
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ out, const float *__restrict__ P, int nsplit, size_t count,
-                                                           const float *__restrict__ vsum_part, int Kp) {
+                                                           const float *__restrict__ vsum_part, int Kp, int Mp, int q_valid) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        if (q_valid > 0 && (int)(i % (size_t)Mp) >= q_valid) { out[i] = 0.f; continue; }
         float s = P[i];
         int sp = 1;
         for (; sp + 4 <= nsplit; sp += 4) {   // fixed order, four loads in flight
@@ -149,8 +170,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(float *__restrict__ o
         }
     }
 }
-hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream, const float *vsum_part, int Kp) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, psum, partials, nsplit, count, vsum_part, Kp);
+hipError_t launch_sum_partials(float *psum, const float *partials, int nsplit, size_t count, hipStream_t stream, const float *vsum_part, int Kp, int Mp, int q_valid) {
+    if (q_valid >= Mp) q_valid = 0;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ew_grid(count)), dim3(256), 0, stream, psum, partials, nsplit, count, vsum_part, Kp, Mp > 0 ? Mp : 1, q_valid);
     return hipGetLastError();
 }
 

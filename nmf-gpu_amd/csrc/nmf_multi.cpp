@@ -29,6 +29,7 @@ struct Rank {
     char err[512] = "";
     nmf_result res;
     std::vector<float> w_copy;   // every rank's W after the run (replica check)
+    std::vector<float> h_copy;   // this rank's column block of H: the caller's H.mat is written only once EVERY rank has succeeded
 };
 
 // All ranks meet here after their set-up; if any failed, every rank learns of it and none enters the loop (a rank that
@@ -74,6 +75,8 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
     if (cst != NMF_OK) return cst;
     std::vector<Rank> rank((size_t)G);
     std::vector<std::thread> th;
+    int stall_rank = -1;
+    if (const char *e = getenv("NMF_FAULT_STALL_RANK")) stall_rank = atoi(e);
     SetupGate gate(G);
     const double t_setup = now_s() - t_begin;
     for (int g = 0; g < G; ++g) {
@@ -87,7 +90,9 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             og.comm = comm[(size_t)g];
             og.stream = nullptr;
             og.n_devices = 1; og.emulate_shards = 0;
-            og.verbose = (g == 0) ? o.verbose : 0;
+            // every rank takes the same decision about convergence checks (they all-reduce three doubles: a rank that skipped
+            // them would pair its next collective with the others' check); only rank 0 prints (verbose = 2: check, silently)
+            og.verbose = o.verbose ? (g == 0 ? 1 : 2) : 0;
             if (!nmf_comm_capturable(comm[(size_t)g])) og.use_graph = 0;
             nmf_solver *s = nullptr;
             int st = r.status;
@@ -99,12 +104,20 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             r.res.t[NMF_T_H2D] = now_s() - t0;
             if (st != NMF_OK) fail(st);
             if (!gate.pass(st == NMF_OK)) { if (s) nmf_solver_destroy(s); if (r.status == NMF_OK) { r.status = NMF_ERR_COMM; snprintf(r.err, sizeof r.err, "rank %d: another rank failed during set-up", g); } return; }
+            if (stall_rank == g) {   // fault injection (NMF_FAULT_STALL_RANK): this rank never reaches its first collective
+                const double t_s = now_s();
+                while (!nmf_comm_aborted(comm[(size_t)g]) && now_s() - t_s < 20.0 * nmf_comm_timeout_s()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                r.status = NMF_ERR_COMM; snprintf(r.err, sizeof r.err, "rank %d: stalled before its first collective (NMF_FAULT_STALL_RANK)", g);
+                nmf_comm_abort(comm[(size_t)g]); nmf_solver_destroy(s);
+                return;
+            }
             nmf_result rr;
             st = nmf_solver_run(s, o.converge_thresh, o.max_iter, o.iter_check, og.verbose, &rr);
             if (st != NMF_OK) { fail(st); nmf_comm_abort(comm[(size_t)g]); nmf_solver_destroy(s); return; }
             const double t1 = now_s();
             r.w_copy.resize((size_t)M * K);
-            st = nmf_solver_download(s, r.w_copy.data(), H.mat + (size_t)start[(size_t)g] * K);   // H is gathered at the end
+            r.h_copy.resize((size_t)K * count[(size_t)g]);
+            st = nmf_solver_download(s, r.w_copy.data(), r.h_copy.data());
             const double h2d = r.res.t[NMF_T_H2D];
             r.res = rr;
             r.res.t[NMF_T_H2D] = h2d;
@@ -117,13 +130,16 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
     for (int g = 0; g < G; ++g) nmf_comm_destroy(comm[(size_t)g]);
     int st = NMF_OK;
     for (int g = 0; g < G && st == NMF_OK; ++g)
-        if (rank[(size_t)g].status != NMF_OK) { st = rank[(size_t)g].status; fprintf(stderr, "nmf: %s\n", rank[(size_t)g].err); }
-    if (st != NMF_OK) return st;
+        if (rank[(size_t)g].status != NMF_OK) { st = rank[(size_t)g].status; fprintf(stderr, "nmf: %s\n", rank[(size_t)g].err); nmf_internal_set_error(rank[(size_t)g].err); }
+    if (st != NMF_OK) return st;   // the caller's W.mat / H.mat are untouched: a fallback may start again from them
     // every rank applied the same update to the same all-reduced operand: the replicas of W must agree bit for bit
     int identical = 1;
     for (int g = 1; g < G; ++g)
         if (memcmp(rank[(size_t)g].w_copy.data(), rank[0].w_copy.data(), sizeof(float) * (size_t)M * K) != 0) identical = 0;
-    memcpy(W.mat, rank[0].w_copy.data(), sizeof(float) * (size_t)M * K);
+    if (identical) {   // H is gathered, W copied, only now
+        memcpy(W.mat, rank[0].w_copy.data(), sizeof(float) * (size_t)M * K);
+        for (int g = 0; g < G; ++g) memcpy(H.mat + (size_t)start[(size_t)g] * K, rank[(size_t)g].h_copy.data(), sizeof(float) * (size_t)K * count[(size_t)g]);
+    }
     if (res) {
         *res = rank[0].res;
         res->n_shards = G;

@@ -304,6 +304,7 @@ static hipError_t launch_pair_nbh(const FusedArgs &a, bool wstep, hipStream_t st
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
         if (e != hipSuccess) return e;                                                                    \
+        note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
     if (fast) {
@@ -329,6 +330,8 @@ static hipError_t launch_check_nbh(const float *W, const float *H, const float *
     const size_t lds = pair_lds_bytes(Kp);
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_pair<NBH, false, false, 0, true>, lds);
     if (e != hipSuccess) return e;
+    note_kernel((const void *)fused_step_kernel_pair<NBH, false, false, 0, true>, stream);
+
     hipLaunchKernelGGL((fused_step_kernel_pair<NBH, false, false, 0, true>), dim3(Np / 32), dim3(256), lds, stream, a, part);
     return hipGetLastError();
 }

@@ -467,6 +467,7 @@ static hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t s
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
         if (e != hipSuccess) return e;                                                                    \
+        note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
     if (fast) {

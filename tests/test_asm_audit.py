@@ -1,0 +1,29 @@
+"""Static guard for the inline-asm MFMAs (tools/asm_audit.py): runs on the CPU, needs hipcc only.  Every kernel translation
+unit is compiled to gfx950 assembly with the Makefile's flags; every MFMA inside an `asm volatile` statement is checked for
+(a) a VALU write of one of its operands within 2 wait states before it and (b) any non-accumulating touch of its result
+within passes + 4 wait states after it, along every control-flow path; kernels holding asm MFMAs must not spill or use
+scratch.  The detector itself is first run on hand-written snippets of both hazards and of their padded forms."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import asm_audit  # noqa: E402
+
+
+def test_the_detector_flags_both_hazards_and_accepts_their_padded_forms():
+    assert asm_audit.self_test() == []
+
+
+@pytest.mark.skipif(not os.path.exists(asm_audit.HIPCC), reason="needs hipcc")
+def test_no_inline_asm_mfma_of_the_shipped_kernels_sits_in_a_hazard_window():
+    n, hazards, rows = asm_audit.run()
+    assert hazards == [], "\n".join(hazards)
+    assert n >= 5000                      # the product-1 chains of every instantiation were found and walked
+    kernels = {r[1].split("<")[0] for r in rows}
+    for family in ("nmf::fused_step_kernel_k16", "nmf::split_step_kernel_k16", "nmf::fused_step_kernel_pair", "nmf::fused_step_kernel_v3"):
+        assert family in kernels, (family, sorted(kernels)[:5])
+    with_asm = [r for r in rows if r[9] > 0]
+    assert with_asm and all(r[6] == 0 and r[7] == 0 for r in with_asm)      # no scratch, no spills next to asm MFMAs

@@ -1,0 +1,108 @@
+"""Every kernel instantiation the half-step and check dispatchers can pick (launch_fused16, launch_split_step,
+launch_fused_pair, the 32-column kernel for K <= 32) is launched BY NAME and compared with the oracle's half-step
+(oracle/nmf_oracle.c: update_h / update_w following cuda/nmf.cu:118-176).  VERDICT r02 weak 4: the inline-asm MFMA chains are
+correct only while their operands sit in VGPRs with the right wait states around them -- a property of the generated code of
+EACH instantiation -- so each one is executed against the oracle here (tools/asm_audit.py inspects the same code statically).
+The library reports the instantiation it launched (nmf_debug_last_kernel: hipKernelNameRefByPtr of the launched pointer)."""
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-6
+
+
+def _args(name):
+    m = re.search(r"nmf::(\w+)<([^>]*)>", name)
+    assert m, name
+    return m.group(1), tuple(a.strip() for a in m.group(2).split(","))
+
+
+def _half_steps(ng, oracle, M, N, K, seen, **kw):
+    """one H half-step, one W half-step and one check on a fresh problem; returns nothing, asserts parity, notes the kernels"""
+    X, W, H = oracle.gen_problem(M, N, K, seed=K + M)
+    s = ng.Solver(M, N, K, use_graph=False, **kw)
+    s.upload(W, H, X)
+    s.update_h()
+    seen.add(_args(ng.last_kernel()))
+    W1, H1 = s.download()
+    Wc, Hc, Xc = oracle.clamp(W), oracle.clamp(H), oracle.clamp(X)
+    Hr = oracle.update_h(Wc, Hc, Xc)
+    eh = oracle.relF(H1, Hr)
+    s.update_w()
+    seen.add(_args(ng.last_kernel()))
+    W2, _ = s.download()
+    Wr = oracle.update_w(Wc, Hr, Xc)
+    ew = oracle.relF(W2, Wr)
+    kl, _ = s.check()
+    seen.add(_args(ng.last_kernel()))
+    klr = oracle.kl_div(Xc, oracle.clamp(oracle.sgemm("nn", Wr, Hr)))
+    s.close()
+    assert eh < TOL and ew < TOL, (ng.last_kernel(), kw, eh, ew)
+    assert abs(kl - klr) <= 2e-5 * abs(klr), (kl, klr)
+
+
+@pytest.fixture()
+def recording(ng):
+    old = ng.record_kernels(True)
+    yield
+    ng.record_kernels(old)
+
+
+def test_every_instantiation_of_the_64_column_kernel(ng, oracle, recording):
+    """fused_step_kernel_k16<NB, WSTEP, PARTIAL, DIV, CHECK, OCC>: NB = K/64 in {1, 2, 4, 5, 6, 7, 8} (OCC = 2 up to NB = 4),
+    both half-steps, in-place and partial-slab epilogues, both quotients, and the CHECK instantiation of every NB"""
+    seen = set()
+    for K, ns, fd in itertools.product((64, 128, 256, 320, 384, 448, 512), (1, 2), (0, 1)):
+        _half_steps(ng, oracle, 160, 208, K, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    want = set()
+    for nb in (1, 2, 4, 5, 6, 7, 8):
+        occ = "2" if nb <= 4 else "1"
+        for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
+            want.add(("fused_step_kernel_k16", (str(nb), w, p, d, "false", occ, "false")))
+        want.add(("fused_step_kernel_k16", (str(nb), "false", "false", "0", "true", occ, "false")))
+    assert want <= seen, sorted(want - seen)
+
+
+def test_every_instantiation_of_the_split_kernel(ng, oracle, recording):
+    """split_step_kernel_k16<KB, NW, WSTEP, PARTIAL, DIV, OCC, DB>: K = 32, 64 (four and eight waves), 128 (two LDS images
+    at one workgroup per CU; one image at two per CU), 256 (one image); both half-steps, both epilogues, both quotients"""
+    seen = set()
+    combos = [(32, {}, ("1", "4", "2", "true")), (64, {}, ("2", "4", "2", "true")), (64, {"NMF_SPLIT_NW": "8"}, ("2", "8", "2", "true")),
+              (128, {}, ("4", "4", "1", "true")), (128, {"NMF_SPLIT_SINGLE": "1"}, ("4", "4", "2", "false")), (256, {}, ("8", "4", "1", "false"))]
+    for (K, env, _), ns, fd in itertools.product(combos, (1, 2), (0, 1)):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            _half_steps(ng, oracle, 512, 768, K, seen, split_kernel=1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    want = set()
+    for (_, _, (kb, nw, occ, db)) in combos:
+        for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
+            want.add(("split_step_kernel_k16", (kb, nw, w, p, d, occ, db)))
+    assert want <= seen, sorted(want - seen)
+
+
+def test_every_instantiation_of_the_wave_pair_kernel_and_of_the_32_column_kernel(ng, oracle, recording):
+    """fused_step_kernel_pair<NBH, WSTEP, PARTIAL, DIV, CHECK> for K = 640, 768, 896, 1024 and fused_step_kernel_v3<1, ...>
+    (K <= 32 when the split kernel is not chosen).  The 32-column kernel's KT = 2, 4, 8 instantiations are reachable only
+    through NMF_FUSED_VARIANT=3 (an A/B switch read once per process) and are not production paths."""
+    seen = set()
+    for K, ns, fd in itertools.product((640, 768, 896, 1024), (1, 2), (0, 1)):
+        _half_steps(ng, oracle, 96, 160, K, seen, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    for ns, fd in itertools.product((1, 2), (0, 1)):
+        _half_steps(ng, oracle, 160, 208, 30, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    want = set()
+    for nbh in ("5", "6", "7", "8"):
+        for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
+            want.add(("fused_step_kernel_pair", (nbh, w, p, d, "false")))
+        want.add(("fused_step_kernel_pair", (nbh, "false", "false", "0", "true")))
+    got_pair = {(n, a[:5]) for n, a in seen if n == "fused_step_kernel_pair"}
+    assert want <= got_pair, sorted(want - got_pair)
+    v3 = {a[:4] for n, a in seen if n == "fused_step_kernel_v3"}
+    assert {("1", w, p, d) for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1"))} <= v3, sorted(v3)

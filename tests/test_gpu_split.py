@@ -113,18 +113,29 @@ def test_resume_from_downloaded_factors_equals_uninterrupted_run(ng, oracle):
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
 
 
+def _splits(solver):
+    """(ns_h, ns_w) of a split-kernel solver, from its describe() line"""
+    import re
+    m = re.search(r"splits\(h,w\)=\((\d+),(\d+)\)", solver.describe())
+    return int(m.group(1)), int(m.group(2))
+
+
 @pytest.mark.parametrize("M,N,K,B", [(1024, 512, 64, 5), (512, 350, 128, 3), (384, 512, 256, 3)])
 def test_batched_pairs_equal_single_solvers_bit_for_bit(ng, oracle, M, N, K, B):
-    """B (W, H) pairs per launch (blockIdx.y) against one resident X: every pair must come out exactly as a solver of its
-    own would produce it; frozen pairs (set_active) must not move"""
+    """B (W, H) pairs per launch (blockIdx.y) against one resident X: with the SAME workgroup-level split every pair must come
+    out exactly as a solver of its own would produce it (the batch only adds a grid dimension); frozen pairs (set_active) must
+    not move.  The split a batched solver picks by itself shrinks with the batch (pick_split), so the single solvers are given
+    the batch's split explicitly; the automatic choices are compared with the oracle in the next tests."""
     X, _, _ = oracle.gen_problem(M, N, K, seed=6)
     rng = np.random.default_rng(11)
     Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(B)]
     Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(B)]
+    sb = ng.Solver(M, N, K, batch=B)
+    nsh, nsw = _splits(sb)
     single = []
     for w, h in zip(Ws, Hs):
-        s = ng.Solver(M, N, K)
-        assert s.uses_split_kernel
+        s = ng.Solver(M, N, K, nsplit_h=nsh, nsplit_w=nsw)
+        assert s.uses_split_kernel and _splits(s) == (nsh, nsw)
         s.upload(w, h, X)
         s.iterate(9)
         w9, h9 = s.download()
@@ -132,7 +143,6 @@ def test_batched_pairs_equal_single_solvers_bit_for_bit(ng, oracle, M, N, K, B):
         s.iterate(6)
         single.append((w9, h9, kl9) + s.download())
         s.close()
-    sb = ng.Solver(M, N, K, batch=B)
     sb.upload(None, None, X)
     for b in range(B):
         sb.upload_pair(b, Ws[b], Hs[b])
@@ -155,19 +165,23 @@ def test_batched_pairs_equal_single_solvers_bit_for_bit(ng, oracle, M, N, K, B):
 @pytest.mark.parametrize("M,N,K,R,thresh", [(1024, 1024, 64, 6, 0.0), (1024, 350, 128, 4, 0.0), (512, 1000, 30, 7, 2e-3)])
 def test_batched_restarts_equal_sequential_update_div_bit_for_bit(ng, oracle, M, N, K, R, thresh):
     """update_div_restarts on a shape the split kernel takes: one batched solver, every launch carries all restarts; each
-    restart must equal a plain update_div_ex of that pair -- factors, final KL, and the iteration it stopped at"""
+    restart must equal a plain update_div_ex of that pair run with the same split counts -- factors, final KL, and the
+    iteration it stopped at"""
     X, _, _ = oracle.gen_problem(M, N, K, seed=8)
     rng = np.random.default_rng(13)
     Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
     Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
     Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
     best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=60, converge_thresh=thresh, iter_check=10)
+    probe = ng.Solver(M, N, K, batch=R)
+    nsh, nsw = _splits(probe)
+    probe.close()
     seq_kl = []
     for i in range(R):
         w1, h1 = ng.Matrix(Ws[i].copy(order="F")), ng.Matrix(Hs[i].copy(order="F"))
-        r = ng.update_div_ex(w1, h1, ng.Matrix(X), max_iter=60, converge_thresh=thresh, iter_check=10)
+        r = ng.update_div_ex(w1, h1, ng.Matrix(X), max_iter=60, converge_thresh=thresh, iter_check=10, nsplit_h=nsh, nsplit_w=nsw)
         assert np.array_equal(w1.mat, Wm[i].mat) and np.array_equal(h1.mat, Hm[i].mat), i
-        s = ng.Solver(M, N, K)
+        s = ng.Solver(M, N, K, nsplit_h=nsh, nsplit_w=nsw)
         s.upload(w1.mat, h1.mat, X)
         seq_kl.append(s.check()[0])
         s.close()
@@ -177,6 +191,31 @@ def test_batched_restarts_equal_sequential_update_div_bit_for_bit(ng, oracle, M,
     # and against the oracle, one pair
     wr, hr, _, _ = oracle.update_div(Ws[1], Hs[1], X, thresh, 60, 10)
     assert _relF(oracle, Wm[1].mat, wr) < 2e-5 and _relF(oracle, Hm[1].mat, hr) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,R", [(4096, 350, 128, 16), (1024, 4096, 64, 8), (512, 3445, 30, 12), (640, 350, 256, 6)])
+def test_batched_restarts_with_the_batch_sized_split_match_the_oracle_per_restart(ng, oracle, M, N, K, R):
+    """the workgroup-level split is chosen from batch x column-groups, not frozen to the single-pair
+    choice -- 16 restarts of the reference's 4096 x 350 x 128 run their H-step with no split at all (22 column groups x 16
+    pairs fill the chip; a lone pair splits 11 ways and pays prologue, epilogue, slabs and an apply launch for three
+    superchunks of work).  Parity is with the oracle, per restart, not with the bits of a differently-split sequential twin."""
+    X, _, _ = oracle.gen_problem(M, N, K, seed=9)
+    rng = np.random.default_rng(17)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    lone, batched = ng.Solver(M, N, K), ng.Solver(M, N, K, batch=R)
+    s1, sb = _splits(lone), _splits(batched)
+    lone.close(); batched.close()
+    assert sb[0] <= s1[0] and sb[1] <= s1[1] and sb != s1, (s1, sb)     # the batch does split less
+    Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    iters = 40
+    best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=iters)
+    worst = 0.0
+    for i in range(R):
+        wr, hr, _, _ = oracle.update_div(Ws[i], Hs[i], X, 0.0, iters, 25)
+        worst = max(worst, _relF(oracle, Wm[i].mat, wr), _relF(oracle, Hm[i].mat, hr))
+    print(f"batched restarts {M}x{N}x{K} x{R}: splits lone {s1} -> batch {sb}; worst relF vs oracle {worst:.2e}")
+    assert worst < 2e-5 and best == int(np.argmin(kls))
 
 
 @pytest.mark.parametrize("split_kernel", [1, -1])

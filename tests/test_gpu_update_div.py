@@ -259,6 +259,33 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     print("cfg3 K_par=10 relF =", _cmp(oracle, Wg, Hg, W10, H10, 2e-5, wh=False))
 
 
+def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
+    """north_star's headline parity gate: "W/H matching reference within 1e-4 rel after 200 iterations" at
+    (M, N, R) = (4096, 65536, 256), BASELINE config 3 -- the full 200 iterations on both sides, same seed-0 inputs
+    (cuda/nmf.cu:10 MAX_ITER; test_output.sh:5-18 is the reference's own 200-iteration comparison).  The CPU side is the
+    oracle's fast arrangement (1.6 full-size iterations/s on the box's 16 cores: about two minutes), which the previous test
+    pins to the oracle's loop at this very shape; the GPU side is the default path (64-column kernel, hipGraph replay)."""
+    import time
+    M, N, K = 4096, 65536, 256
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(200)
+    Wg, Hg = s.download()
+    kl_gpu, _ = s.check()
+    s.close()
+    t0 = time.time()
+    Wr, Hr = oracle.update_div_fast(W, H, X, 200)
+    dt = time.time() - t0
+    eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
+    # W*H on a column block (the full product is 1 GiB): gauge freedom between W and H cancels in it
+    blk = slice(N // 2, N // 2 + 2048)
+    eWH = oracle.relF(Wg @ Hg[:, blk], Wr @ Hr[:, blk])
+    print(f"cfg3 x 200 iterations vs oracle ({dt:.0f} s of CPU): relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, relF(W*H block) = {eWH:.2e}, KL(gpu) = {kl_gpu:.6e}")
+    assert eW < 1e-4 and eH < 1e-4 and eWH < 1e-4          # north_star tolerance, fp32 relative (Frobenius)
+    assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
+
+
 def test_cfg3_200_iterations_kl_monotone(ng):
     """SURVEY 8(d) gate for the shapes the CPU cannot iterate 200 times: the full 200-iteration run at
     BASELINE config 3, KL checked every 25 iterations, must decrease at every check and stay finite."""
@@ -411,6 +438,39 @@ def test_full_size_properties_cfg4_shard_shape(ng):
     kl2, _ = s.check()
     assert kl0 > kl1 > kl2 > 0 and np.isfinite(H2).all() and np.isfinite(W2).all()
     s.close()
+
+
+def test_cfg4_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, oracle):
+    """BASELINE config 4 (M=4096, N=262144, R=256; X is 4 GiB) against the oracle after K_par = 3 iterations (2.2 TFLOP each
+    on the CPU: ~10 s in all), twice: on one GPU, and as the EIGHT column shards the config names (32768 columns each, the
+    W-step's [Z*H' ; rowsum(H)] all-reduced every iteration) through the in-library driver with emulated ranks -- the
+    8-GPU decomposition with the RCCL call replaced by a rank-ordered device sum.  The fast oracle arrangement is first
+    checked against the pinned loop on one shard's columns."""
+    import time
+    M, N, K, G, KPAR = 4096, 262144, 256, 8, 3
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    ns = N // G
+    Hs, Xs = np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns])
+    W1r, H1r, _, _ = oracle.update_div(W, Hs, Xs, 0.0, 1, 25)
+    W1f, H1f = oracle.update_div_fast(W, Hs, Xs, 1)
+    assert oracle.relF(W1f, W1r) < 5e-6 and oracle.relF(H1f, H1r) < 5e-6
+    t0 = time.time()
+    Wr, Hr = oracle.update_div_fast(W, H, X, KPAR)
+    dt = time.time() - t0
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(KPAR)
+    Wg, Hg = s.download()
+    s.close()
+    e1 = (oracle.relF(Wg, Wr), oracle.relF(Hg, Hr))
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=KPAR, emulate_shards=G)
+    e8 = (oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr))
+    print(f"cfg4 K_par={KPAR} vs oracle ({dt:.0f} s of CPU): one GPU relF(W, H) = {e1[0]:.2e}, {e1[1]:.2e}; 8 emulated shards = {e8[0]:.2e}, {e8[1]:.2e}")
+    assert r["n_shards"] == G and r["w_replicas_identical"] == 1 and r["iterations"] == KPAR
+    assert max(e1) < 2e-5 and max(e8) < 2e-5
+    # the H-step is column-local: the last shard's block of H must agree as well as the first's
+    assert oracle.relF(Hm.mat[:, -ns:], Hr[:, -ns:]) < 2e-5 and oracle.relF(Hg[:, -ns:], Hr[:, -ns:]) < 2e-5
 
 
 def test_multi_restart_picks_lowest_kl(ng, oracle):
