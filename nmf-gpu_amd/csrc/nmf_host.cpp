@@ -108,6 +108,7 @@ struct nmf_solver {
     // split path (nmf_split16.hip): four waves per 16 owned columns, normalisers summed in-stream, `batch` (W, H) pairs per launch
     bool split = false;
     int batch = 1;
+    int split_batch = 1;           // restarts in the whole update_div_restarts call this solver serves a share of (>= batch): what pick_split sees
     int ns_h = 1, ns_w = 1;        // workgroup-level splits of the reduction dimension on the split path
     int nw_h = 4, nw_w = 4;        // waves per workgroup of the two half-steps (8 where K = 64 and the reduction length allows)
     float *vpart = nullptr;        // [batch][ns][Kp] per-split sums of the streamed factor
@@ -233,18 +234,31 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : (kp == 128 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
-// workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.  One
-// workgroup per CU is the target for a single pair; a launch that carries `batch` pairs (restarts) already hands out
-// batch x column-groups workgroups, and a workgroup-level split then only multiplies fixed costs (prologue, epilogue, slabs and
-// their apply launch): the split shrinks with the batch and disappears once batch x column-groups fills the chip.  `batch` is
-// the restart count of the whole update_div_restarts call (not of one device's or one chunk's share), so that a restart gets
-// the same split -- hence the same bits -- wherever it runs.
-static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1) {
+// workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
+// A single pair: one workgroup per CU is the target, never more workgroups than CUs (a second round costs more than the
+// shorter loop saves: 264 workgroups on the gold shape's H-step took 20.4 us against 15.5 us for 176).
+// A launch that carries `batch` pairs (restarts) already hands out batch x column-groups workgroups, and every further split
+// only multiplies fixed costs (prologue, epilogue, slabs, the apply launch): the split shrinks with the batch and stops at
+// `wg_per_cu` workgroups per CU -- two where the LDS image allows it (K <= 64; K = 128 with a batch: one image), because a
+// co-resident workgroup fills the other's quotient / barrier / first-touch time.  Measured (tools/restart_split_sweep.py,
+// profiles/r03_restart_sweep.log), 16 restarts of 4096 x 350 x 128, H-step split 1 / 2 / 4 / 11: 295 / 263 / 266 / 275 us per
+// iteration of the batch; 16 x cfg2, W-step split 1 / 2 / 4: 319 / 323 / 332.  Splits that divide the superchunk count evenly
+// are preferred (32 superchunks three ways -- 11, 11, 10 -- cost 99 us where four ways cost 88).  `batch` is the restart count
+// of the whole update_div_restarts call (not of one device's or one chunk's share), so that a restart gets the same split --
+// hence the same bits -- wherever it runs.
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1, int wg_per_cu = 1) {
     const int tasks = q_valid / 16, nsc = p_extent / sc_rows;
-    if (tasks >= 192 || nsc <= 1) return 1;
-    if (batch < 1) batch = 1;
-    const long groups = (long)tasks * batch;
-    int S = groups >= 256 ? 1 : (int)(256 / groups);   // never more workgroups than CUs: a second round costs more than the shorter loop saves
+    if (nsc <= 1) return 1;
+    int S;
+    if (batch <= 1) {
+        if (tasks >= 192) return 1;
+        S = 256 / tasks;
+    } else {
+        const long groups = (long)tasks * batch, target = 256L * (wg_per_cu > 1 ? 2 : 1);
+        if (groups >= target) return 1;
+        S = (int)((target + groups - 1) / groups);
+        for (int d = S; d <= 2 * S && d <= nsc; ++d) if (nsc % d == 0) { S = d; break; }   // an even division if one is near
+    }
     if (S < 1) S = 1;
     if (S > nsc) S = nsc;
     const int scps = (nsc + S - 1) / S;
@@ -299,13 +313,15 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         s->nw_h = (nw8 && s->Mp % 256 == 0) ? 8 : 4;
         s->nw_w = (nw8 && s->Np % 256 == 0) ? 8 : 4;
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call (pick_split)
-        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb);
-        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb);
+        s->split_batch = sb;
+        const int wpc = (s->Kp <= 64 || (s->Kp == 128 && sb > 1)) ? 2 : 1;   // workgroups the LDS image lets share a CU (split_args: single_image)
+        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb, wpc);
+        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb, wpc);
         const int nsc_h = s->Mp / (32 * s->nw_h), nsc_w = s->Np / (32 * s->nw_w);
         if (s->ns_h > nsc_h) s->ns_h = nsc_h;
         if (s->ns_w > nsc_w) s->ns_w = nsc_w;
         s->nsplit_h = s->ns_h; s->nsplit_w = s->ns_w;
-        size_t pc = (size_t)s->ns_w * mk;                  // the W-step may always need slabs (sharded runs)
+        size_t pc = (s->ns_w > 1 || batch == 1) ? (size_t)s->ns_w * mk : 0;   // an unbatched solver's W-step may always need slabs (sharded runs)
         if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
         ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
         zero_slabs = true;   // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
@@ -345,6 +361,8 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
     if ((size_t)K * N > s->staging_count) s->staging_count = (size_t)K * N;
+    // a batched solver moves all its pairs through staging behind ONE synchronisation (upload_pairs / download_pairs)
+    if (batch > 1 && (size_t)batch * ((size_t)M * K + (size_t)K * N) > s->staging_count) s->staging_count = (size_t)batch * ((size_t)M * K + (size_t)K * N);
     ar.reserve((void **)&s->staging, s->staging_count * sizeof(float));
     for (auto &r : ar.reqs) if (zero_slabs && (r.p == (void **)&s->partials || r.p == (void **)&s->psum_owned)) r.zero = true;
     NMFCHK(ar.commit(&s->arena, s->stream));
@@ -491,6 +509,47 @@ extern "C" int nmf_solver_set_active(nmf_solver *s, const int *flags) {
     return NMF_OK;
 }
 
+// All n pairs of a batched solver through the staging buffer (sized for it by solver_init) behind one synchronisation: a
+// per-pair upload / download costs two stream synchronisations each, which is a third of a 16-restart call on a small problem
+static int upload_pairs(nmf_solver *s, const matrix *W, const matrix *H, int n) {
+    if (!s || n < 1 || n > s->batch) return NMF_ERR_ARG;
+    const size_t mk = (size_t)s->M * s->K, kn = (size_t)s->K * s->N;
+    if (s->staging_count < (size_t)n * (mk + kn)) {
+        for (int b = 0; b < n; ++b) NMFCHK(nmf_solver_upload_pair(s, b, W[b].mat, H[b].mat));
+        return NMF_OK;
+    }
+    s->normW_fresh = false;
+    for (int b = 0; b < n; ++b) {
+        float *sw = s->staging + (size_t)b * (mk + kn), *sh = sw + mk;
+        HIPCHK(hipMemcpyAsync(sw, W[b].mat, mk * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(launch_pad_copy(s->W + (size_t)b * s->Mp * s->Kp, s->Mp, s->Kp, sw, s->M, s->K, true, nullptr, s->stream));
+        HIPCHK(hipMemcpyAsync(sh, H[b].mat, kn * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(launch_pad_copy(s->H + (size_t)b * s->Kp * s->Np, s->Kp, s->Np, sh, s->K, s->N, true, nullptr, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NMF_OK;
+}
+static int download_pairs(nmf_solver *s, const matrix *W, const matrix *H, int n) {
+    if (!s || n < 1 || n > s->batch) return NMF_ERR_ARG;
+    const size_t mk = (size_t)s->M * s->K, kn = (size_t)s->K * s->N;
+    if (s->staging_count < (size_t)n * (mk + kn)) {
+        for (int b = 0; b < n; ++b) NMFCHK(nmf_solver_download_pair(s, b, W[b].mat, H[b].mat));
+        return NMF_OK;
+    }
+    for (int b = 0; b < n; ++b) {
+        float *sw = s->staging + (size_t)b * (mk + kn), *sh = sw + mk;
+        HIPCHK(launch_unpad_copy(sw, s->M, s->K, s->W + (size_t)b * s->Mp * s->Kp, s->Mp, s->stream));
+        HIPCHK(launch_unpad_copy(sh, s->K, s->N, s->H + (size_t)b * s->Kp * s->Np, s->Kp, s->stream));
+    }
+    for (int b = 0; b < n; ++b) {
+        float *sw = s->staging + (size_t)b * (mk + kn), *sh = sw + mk;
+        HIPCHK(hipMemcpyAsync(W[b].mat, sw, mk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(H[b].mat, sh, kn * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return NMF_OK;
+}
+
 // --------------------------------------------------------------------- tracing: roctx ranges
 // One range per piece of an iteration (H-step, W-step, sums, apply, check, all-reduce) around its enqueue, so that
 // `rocprofv3 --marker-trace --kernel-trace` attributes kernels to pieces.  The roctx library is dlopen()ed, and only when the
@@ -582,7 +641,7 @@ static SplitArgs split_args(nmf_solver *s) {
     a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
     a.nw_h = s->nw_h; a.nw_w = s->nw_w;
     // K = 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
-    a.single_image = (s->Kp == 128 && s->batch > 1 && !getenv("NMF_SPLIT_DOUBLE")) || (s->Kp == 128 && getenv("NMF_SPLIT_SINGLE") != nullptr);
+    a.single_image = (s->Kp == 128 && s->split_batch > 1 && !getenv("NMF_SPLIT_DOUBLE")) || (s->Kp == 128 && getenv("NMF_SPLIT_SINGLE") != nullptr);
     a.Mv = (s->M + 31) & ~31; a.Nv = (s->N + 31) & ~31;
     a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np;
     a.active = s->active_d;
@@ -1335,9 +1394,14 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
     // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
     // batch outlasts its own enqueue by far): 16 restarts x 200 iterations on the gold shape take 67 ms eagerly, 90 ms captured
     if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
+    const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;   // wall time of every phase of the call, to stderr
+    double tp = now_s();
+    auto phase = [&](const char *what) { if (trace) { const double t = now_s(); fprintf(stderr, "nmf restarts: %-28s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };
     nmf_solver *s = nullptr;
     NMFCHK(create_batched(&s, M, N, K, B, &o, split_batch));
+    phase("solver (allocation)");
     int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
+    phase("X upload");
     const int iter_check = o.iter_check > 0 ? o.iter_check : NMF_ITER_CHECK_DEFAULT;
     const bool checks = (o.converge_thresh > 0.f) || o.verbose;
     std::vector<double> prev((size_t)B), cur((size_t)B), rl1((size_t)B);
@@ -1346,9 +1410,10 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
     double best_kl = 0.0;
     for (int base = 0; st == NMF_OK && base < n_restarts; base += B) {
         const int n = (n_restarts - base < B) ? (n_restarts - base) : B;
-        for (int b = 0; st == NMF_OK && b < n; ++b) st = nmf_solver_upload_pair(s, b, W[base + b].mat, H[base + b].mat);
+        if (st == NMF_OK) st = upload_pairs(s, W + base, H + base, n);
         for (int b = 0; b < B; ++b) act[(size_t)b] = b < n;
-        if (st == NMF_OK) st = nmf_solver_set_active(s, act.data());
+        if (st == NMF_OK && (n < B || base > 0)) st = nmf_solver_set_active(s, act.data());   // a full first batch: every flag is still 1
+        phase("pair uploads");
         if (st == NMF_OK && checks) {
             st = nmf_solver_check_all(s, prev.data(), rl1.data());
             if (o.verbose) for (int b = 0; b < n; ++b) printf("restart %d iter %5d  kl-divergence %.6e  rel-L1 error %.6e\n", gidx ? gidx[base + b] : base + b, 0, prev[(size_t)b], rl1[(size_t)b]);
@@ -1374,15 +1439,19 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
                 if (st == NMF_OK && changed) st = nmf_solver_set_active(s, act.data());
             }
         }
+        if (trace && st == NMF_OK) { st = nmf_solver_sync(s); phase("iterations"); }
         if (st == NMF_OK) st = nmf_solver_check_all(s, cur.data(), nullptr);
+        phase("final KL of every pair");
+        if (st == NMF_OK) st = download_pairs(s, W + base, H + base, n);
+        phase("pair downloads");
         for (int b = 0; st == NMF_OK && b < n; ++b) {
-            st = nmf_solver_download_pair(s, b, W[base + b].mat, H[base + b].mat);
             if (kl) kl[base + b] = cur[(size_t)b];
             if (best_i < 0 || cur[(size_t)b] < best_kl) { best_i = base + b; best_kl = cur[(size_t)b]; }
         }
     }
     if (st == NMF_OK && hipGetLastError() != hipSuccess) { set_err("update_div_restarts: a kernel launch failed"); st = NMF_ERR_HIP; }
     nmf_solver_destroy(s);
+    phase("solver destroyed");
     if (st == NMF_OK && best) *best = best_i;
     return st;
 }

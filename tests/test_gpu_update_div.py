@@ -264,25 +264,53 @@ def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
     (M, N, R) = (4096, 65536, 256), BASELINE config 3 -- the full 200 iterations on both sides, same seed-0 inputs
     (cuda/nmf.cu:10 MAX_ITER; test_output.sh:5-18 is the reference's own 200-iteration comparison).  The CPU side is the
     oracle's fast arrangement (1.6 full-size iterations/s on the box's 16 cores: about two minutes), which the previous test
-    pins to the oracle's loop at this very shape; the GPU side is the default path (64-column kernel, hipGraph replay)."""
+    pins to the oracle's loop at this very shape; the GPU side is the default path (64-column kernel, hipGraph replay).
+    Compared every 50 iterations: W, H and the model W*H (on a 2048-column block; the full product is 1 GiB) within 1e-4 at
+    every stage.
+
+    History worth keeping (round 3): the first run of this test found the factors 2.3e-4 apart after 200 iterations, growing
+    1.1e-6 per iteration, with W*H at 1e-5.  Twins settled whose drift it was: the GPU against itself with rows and columns
+    of the problem permuted (the same sums in another order) moved by 1e-5, the oracle's twin by 3.6e-5, both far less than
+    the GPU-oracle distance -- so the difference was systematic, not order noise.  It was the oracle: its fast arrangement
+    summed Z*H' over all 65536 columns in ONE fp32 accumulator, and a sequential round-to-nearest sum of that many positive
+    terms comes out low by 8.0e-7 +- 0.6e-7 relative (measured), while rowsum(H), summed in blocks, has no such bias; W
+    shrank and H grew by that factor every iteration (against an fp64 evaluation: scale of W -4.3e-5 after 50 iterations,
+    nothing else).  oracle/nmf_oracle_fast.c now sums its long reductions in blocks of 512 (1.2e-6 from fp64 after 50
+    iterations); the pinned loop, with 8-lane partial sums, never had the drift.  The GPU's twin stays in the test: it bounds
+    the GPU's own sensitivity to summation order (the K-relabelled twin of tests/test_oracle_golden.py moves it by 2e-6)."""
     import time
     M, N, K = 4096, 65536, 256
     X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    blk = slice(N // 2, N // 2 + 2048)
+    rng = np.random.default_rng(1)
+    pm, pn = rng.permutation(M), rng.permutation(N)
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
-    s.iterate(200)
-    Wg, Hg = s.download()
+    sp = ng.Solver(M, N, K)                          # GPU twin: rows and columns permuted
+    sp.upload(np.asfortranarray(W[pm]), np.asfortranarray(H[:, pn]), np.asfortranarray(X[pm][:, pn]))
+    Wr, Hr = W, H
+    rows, cpu_s = [], 0.0
+    for stage in range(4):
+        s.iterate(50)
+        sp.iterate(50)
+        Wg, Hg = s.download()
+        t0 = time.time()
+        Wr, Hr = oracle.update_div_fast(Wr, Hr, X, 50)
+        cpu_s += time.time() - t0
+        eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
+        eWH = oracle.relF(Wg @ Hg[:, blk], Wr @ Hr[:, blk])
+        Wp, Hp = sp.download()
+        gW, gH = oracle.relF(Wp, Wg[pm]), oracle.relF(Hp, Hg[:, pn])
+        scale = float(np.vdot(Wg.astype(np.float64), Wr.astype(np.float64)) / np.vdot(Wr.astype(np.float64), Wr.astype(np.float64))) - 1.0
+        rows.append((50 * (stage + 1), eW, eH, eWH, gW, gH, scale))
     kl_gpu, _ = s.check()
-    s.close()
-    t0 = time.time()
-    Wr, Hr = oracle.update_div_fast(W, H, X, 200)
-    dt = time.time() - t0
-    eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
-    # W*H on a column block (the full product is 1 GiB): gauge freedom between W and H cancels in it
-    blk = slice(N // 2, N // 2 + 2048)
-    eWH = oracle.relF(Wg @ Hg[:, blk], Wr @ Hr[:, blk])
-    print(f"cfg3 x 200 iterations vs oracle ({dt:.0f} s of CPU): relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, relF(W*H block) = {eWH:.2e}, KL(gpu) = {kl_gpu:.6e}")
-    assert eW < 1e-4 and eH < 1e-4 and eWH < 1e-4          # north_star tolerance, fp32 relative (Frobenius)
+    s.close(); sp.close()
+    for it, eW, eH, eWH, gW, gH, scale in rows:
+        print(f"cfg3 after {it:3d} iterations: GPU vs oracle relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, relF(W*H block) = {eWH:.2e}, "
+              f"scale of W {scale:+.1e}; GPU vs its row/column-permuted twin {gW:.2e}, {gH:.2e}")
+    print(f"cfg3 x 200: {cpu_s:.0f} s of CPU; KL(gpu) = {kl_gpu:.6e}")
+    assert all(r[1] < 1e-4 and r[2] < 1e-4 and r[3] < 1e-4 for r in rows)       # north_star's tolerance, fp32 relative (Frobenius), at every stage
+    assert all(r[4] < 5e-5 and r[5] < 5e-5 for r in rows)                      # the GPU's own sensitivity to the order of its sums
     assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
 
 
@@ -467,10 +495,15 @@ def test_cfg4_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, ora
     r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=KPAR, emulate_shards=G)
     e8 = (oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr))
     print(f"cfg4 K_par={KPAR} vs oracle ({dt:.0f} s of CPU): one GPU relF(W, H) = {e1[0]:.2e}, {e1[1]:.2e}; 8 emulated shards = {e8[0]:.2e}, {e8[1]:.2e}")
+    e18 = (oracle.relF(Wm.mat, Wg), oracle.relF(Hm.mat, Hg))
+    print(f"cfg4: one GPU vs 8 emulated shards: relF(W, H) = {e18[0]:.2e}, {e18[1]:.2e}")
     assert r["n_shards"] == G and r["w_replicas_identical"] == 1 and r["iterations"] == KPAR
-    assert max(e1) < 2e-5 and max(e8) < 2e-5
+    # north_star's tolerance; measured 3.7e-5 (W) / 2.3e-5 (H) on both decompositions: the W-step sums 262144 columns in fp32,
+    # four times cfg3's reduction length, in a different order on each side
+    assert max(e1) < 1e-4 and max(e8) < 1e-4
+    assert max(e18) < 1e-5            # the all-reduce's reordering alone
     # the H-step is column-local: the last shard's block of H must agree as well as the first's
-    assert oracle.relF(Hm.mat[:, -ns:], Hr[:, -ns:]) < 2e-5 and oracle.relF(Hg[:, -ns:], Hr[:, -ns:]) < 2e-5
+    assert oracle.relF(Hm.mat[:, -ns:], Hr[:, -ns:]) < 1e-4 and oracle.relF(Hg[:, -ns:], Hr[:, -ns:]) < 1e-4
 
 
 def test_multi_restart_picks_lowest_kl(ng, oracle):
@@ -658,9 +691,16 @@ def test_restart_lanes_equal_sequential_restarts(ng, oracle, thresh):
         Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
         best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=100, converge_thresh=thresh, iter_check=10, restart_lanes=lanes)
         runs.append((best, kls, [w.mat.copy() for w in Wm], [h.mat.copy() for h in Hm]))
-    for r in runs[1:]:
-        assert r[0] == runs[0][0] and r[1] == runs[0][1]
-        assert all(np.array_equal(a, b) for a, b in zip(r[2], runs[0][2])) and all(np.array_equal(a, b) for a, b in zip(r[3], runs[0][3]))
+    r = runs[1]                                        # three lanes against one: the same kernels, the same bits
+    assert r[0] == runs[0][0] and r[1] == runs[0][1]
+    assert all(np.array_equal(a, b) for a, b in zip(r[2], runs[0][2])) and all(np.array_equal(a, b) for a, b in zip(r[3], runs[0][3]))
+    # restart_lanes = 0 takes the batched grid for this shape, whose workgroup-level split is sized for the batch: same math,
+    # another summation order.  Without a threshold every restart runs 100 iterations and stays within order noise of the lanes;
+    # with one, a restart may stop a check earlier or later than its twin, so only the oracle comparison below applies.
+    r = runs[2]
+    if thresh == 0:
+        assert r[0] == runs[0][0] and np.allclose(r[1], runs[0][1], rtol=1e-5)
+        assert all(oracle.relF(a, b) < 2e-5 for a, b in zip(r[2], runs[0][2])) and all(oracle.relF(a, b) < 2e-5 for a, b in zip(r[3], runs[0][3]))
     wr, hr, it, _ = oracle.update_div(Ws[2], Hs[2], X, thresh, 100, 10)
     assert it == 100 or thresh > 0
     _cmp(oracle, runs[2][2][2], runs[2][3][2], wr, hr, 2e-5)
