@@ -138,6 +138,12 @@ def main():
         args.gpus = world
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on stdout when its first communicator comes up
+    # (torch's bundled 2.26.6 does, on every rank): keep the real stdout aside for the JSON line and send everything else that
+    # any library writes to file descriptor 1 to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import nmf_gpu_amd as ng
     ng.lib()   # fail loudly if the HIP library is missing
@@ -279,7 +285,24 @@ def main():
     ms_k = max(ms_h, ms_w)
     k_flops = 4.0 * M * Nloc * K
     achieved = k_flops / (ms_k * 1e-3) / 1e12
-    if dist is not None and pieces is not None:      # the slowest rank's figures
+    if shard is not None:
+        # torch.distributed path: event pairs on the shard's stream around the all-reduce and around the whole iteration
+        ev = []
+        with torch.cuda.stream(shard.stream):
+            for _ in range(args.steps):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                e[0].record(shard.stream); shard.update_h(); buf = shard.w_partial()
+                e[1].record(shard.stream); shard.allreduce_sum(buf)
+                e[2].record(shard.stream); shard.w_apply()
+                e[3].record(shard.stream)
+                ev.append(e)
+        shard.stream.synchronize()
+        ar_t = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+        tot_t = sum(e[0].elapsed_time(e[3]) for e in ev) / args.steps
+        pv = torch.tensor([ar_t, tot_t - ar_t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pv, op=dist.ReduceOp.MAX)
+        ar_ms, comp_ms = float(pv[0]), float(pv[1])
+    elif dist is not None and pieces is not None:      # the slowest rank's figures
         pv = torch.tensor([pieces["allreduce"], pieces["h_step"] + pieces["w_step"] + pieces["sums"] + pieces["apply"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(pv, op=dist.ReduceOp.MAX)
         ar_ms, comp_ms = float(pv[0]), float(pv[1])
@@ -336,7 +359,8 @@ def main():
                 out["rccl"] = f"unavailable ({e})"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(M, Ntot, K, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     s.close()
     if comm is not None:
         comm.close()

@@ -121,6 +121,11 @@ struct nmf_solver {
     unsigned *range_flag = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // check_all of a batched solver: the pairs' checks are a few workgroups each (the reference's 4096 x 350 x 128: six), so
+    // they run side by side on helper streams, forked from and joined to `stream` by events
+    static constexpr int kAux = 4;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
     nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
     bool external_reduce = false;  // sharded, caller reduces the partial buffer
     bool comm_warm = false;        // one eager all-reduce has run on this communicator (before any capture)
@@ -166,13 +171,21 @@ struct Arena {
         size_t total = 0;
         for (auto &r : reqs) total += (r.bytes + 255) & ~(size_t)255;
         char *base = nullptr;
+        const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;
+        const double t0 = now_s();
         HIPCHK(hipMalloc((void **)&base, total ? total : 256));
+        const double t1 = now_s();
         *base_out = base;
-        size_t off = 0;
-        for (auto &r : reqs) {
-            *r.p = base + off;
-            if (r.zero) HIPCHK(hipMemsetAsync(base + off, 0, r.bytes, st));
-            off += (r.bytes + 255) & ~(size_t)255;
+        // one 16-byte-store kernel over the whole arena instead of a hipMemsetAsync per zero-initialised buffer (those took 18-21 ms
+        // on the gold shape's buffers: nmf_kernels.h, launch_zero); buffers that need no zeroing are cleared too, at ~3 TB/s
+        size_t off = 0, zeroed = total;
+        for (auto &r : reqs) { *r.p = base + off; off += (r.bytes + 255) & ~(size_t)255; }
+        HIPCHK(launch_zero(base, total, st));
+        if (trace) {
+            const double t2 = now_s();
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "nmf arena: %.1f MiB: hipMalloc %.3f ms, %.1f MiB of memsets enqueued in %.3f ms, drained in %.3f ms\n", total / 1048576.0, (t1 - t0) * 1e3,
+                    zeroed / 1048576.0, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
         }
         return NMF_OK;
     }
@@ -348,7 +361,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         ar.reserve((void **)&s->partials, ((size_t)s->nsplit_w * mk) * sizeof(float));
         s->chk_groups = reduce_num_groups(mn);
     }
-    ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups);
+    ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups * (size_t)batch);   // one set per pair: check_all runs the pairs' checks side by side
     ar.reserve((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch);
     s->chk_host.assign(3 * (size_t)batch, 0.0);
     if (batch > 1) ar.reserve((void **)&s->active_d, sizeof(int) * (size_t)batch);   // from the start: captured graphs never hold a stale null pointer
@@ -356,7 +369,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     if (path == NMF_PATH_FUSED) {
         ar.reserve((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups);
         ar.reserve((void **)&s->xc3, sizeof(double) * 3, true);
-        ar.reserve((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks));
+        ar.reserve((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks) * (size_t)batch);
     }
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
@@ -391,6 +404,11 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_graphs(s);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int i = 0; i < nmf_solver::kAux; ++i) {
+        if (s->aux[i]) (void)hipStreamDestroy(s->aux[i]);
+        if (s->aux_join[i]) (void)hipEventDestroy(s->aux_join[i]);
+    }
+    if (s->aux_fork) (void)hipEventDestroy(s->aux_fork);
     if (s->arena) (void)hipFree(s->arena);
     if (s->active_own) (void)hipFree(s->active_own);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -1022,11 +1040,31 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     if (s->path != NMF_PATH_FUSED) { set_err("check_all: fused path only"); return NMF_ERR_UNSUPPORTED; }
     hipStream_t st = s->stream;
     NMFCHK(ensure_x_consts(s));
-    for (int b = 0; b < s->batch; ++b) {
-        const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
-        HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
-        HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
+    const int nlanes = s->batch < nmf_solver::kAux ? s->batch : nmf_solver::kAux;
+    bool fork = s->batch > 1;
+    if (fork && !s->aux_fork) {   // helper streams, created at the first use
+        if (hipEventCreateWithFlags(&s->aux_fork, hipEventDisableTiming) != hipSuccess) fork = false;
+        for (int i = 0; fork && i < nmf_solver::kAux; ++i)
+            if (hipStreamCreateWithFlags(&s->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->aux_join[i], hipEventDisableTiming) != hipSuccess) fork = false;
+        if (!fork) { (void)hipGetLastError(); if (s->aux_fork) { (void)hipEventDestroy(s->aux_fork); s->aux_fork = nullptr; } }
     }
+    if (fork) {
+        HIPCHK(hipEventRecord(s->aux_fork, st));
+        for (int i = 0; i < nlanes; ++i) HIPCHK(hipStreamWaitEvent(s->aux[i], s->aux_fork, 0));
+    }
+    const size_t part_stride = 3 * (size_t)s->chk_groups, sum_stride = (size_t)s->Kp + kSum64Blocks;
+    for (int b = 0; b < s->batch; ++b) {
+        hipStream_t sb = fork ? s->aux[b % nlanes] : st;
+        double *part = s->chk_part + (fork ? (size_t)b * part_stride : 0), *sum64 = s->sum64 + (fork ? (size_t)b * sum_stride : 0);
+        const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
+        HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, part, sb));
+        HIPCHK(launch_check_compose(part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, sum64, s->chk_out + 3 * (size_t)b, sb));
+    }
+    if (fork)
+        for (int i = 0; i < nlanes; ++i) {
+            HIPCHK(hipEventRecord(s->aux_join[i], s->aux[i]));
+            HIPCHK(hipStreamWaitEvent(st, s->aux_join[i], 0));
+        }
     HIPCHK(hipMemcpyAsync(s->chk_host.data(), s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < s->batch; ++b) {
@@ -1391,9 +1429,9 @@ constexpr int kMaxRestartBatch = 64;
 static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     nmf_opts o = o_in;
-    // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
-    // batch outlasts its own enqueue by far): 16 restarts x 200 iterations on the gold shape take 67 ms eagerly, 90 ms captured
-    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
+    // as in update_div_ex: a run too short does not earn back the capture and instantiation of its graphs (1-2 ms); the work of
+    // a batch counts B-fold (16 x cfg2: 319 us per iteration of the batch replayed, 332 us launched eagerly)
+    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)B * (double)o.max_iter < 2e12) ? -1 : 1;
     const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;   // wall time of every phase of the call, to stderr
     double tp = now_s();
     auto phase = [&](const char *what) { if (trace) { const double t = now_s(); fprintf(stderr, "nmf restarts: %-28s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };

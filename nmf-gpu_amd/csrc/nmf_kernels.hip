@@ -32,6 +32,16 @@ namespace nmf {
 static bool use_pair(int Kp) { return Kp > 512; }   // two waves per 16 owned columns, K split between them (nmf_pair16.hip)
 static bool use_k16(int Kp) { return !use_pair(Kp) && (Kp > 256 || (Kp >= 64 && fused_variant() == 0)); }
 
+__global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+hipError_t launch_zero(void *p, size_t bytes, hipStream_t stream) {
+    if (!bytes) return hipSuccess;
+    if ((bytes & 15) || ((uintptr_t)p & 15)) return hipMemsetAsync(p, 0, bytes, stream);
+    hipLaunchKernelGGL(zero_kernel, dim3(ew_grid(bytes / 16)), dim3(256), 0, stream, (uint4 *)p, bytes / 16);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
     if ((a.Mp | a.Np | a.Kp) & 31) return hipErrorInvalidValue;
     if (a.nsplit < 1 || (a.nsplit > 1 && !a.partial)) return hipErrorInvalidValue;
