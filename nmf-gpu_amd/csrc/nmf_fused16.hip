@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     int q0 = (qblk * 4 + wave) * 16;
     const bool active = q0 < Q;
     if (!active) q0 = Q - 16;
-    const float *__restrict__ V = WSTEP ? a.H : a.W;
-    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const size_t pair = CHECK ? (size_t)blockIdx.y : 0;   // the check of a batched solver: one launch over all its pairs (FusedArgs::strideW)
+    const float *__restrict__ V = (WSTEP ? a.H : a.W) + pair * (WSTEP ? a.strideH : a.strideW);
+    const float *__restrict__ U = (WSTEP ? a.W : a.H) + pair * (WSTEP ? a.strideW : a.strideH);
     const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
     const int nchunks = P / 32;
     const int cps = (nchunks + nsplit - 1) / nsplit;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     }
     if (CHECK) {
         if (!active) { kl = 0.0; dabs = 0.0; xabs = 0.0; }
-        block_reduce3(kl, dabs, xabs, chk_part + 3 * (size_t)blockIdx.x, tid);
+        block_reduce3(kl, dabs, xabs, chk_part + 3 * ((size_t)blockIdx.x + pair * gridDim.x), tid);
         return;
     }
     if (!active) return;
@@ -349,16 +350,17 @@ static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t s
 }
 
 template <int NB, int OCC>
-static hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+static hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                                   int batch, size_t strideW, size_t strideH) {
     FusedArgs a;
     a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
     a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
+    a.strideW = strideW; a.strideH = strideH;
     const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, lds);
     if (e != hipSuccess) return e;
     note_kernel((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, stream);
-
-    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, part);
+    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64, (unsigned)batch), dim3(256), lds, stream, a, part);
     return hipGetLastError();
 }
 
@@ -410,16 +412,17 @@ hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream) {
     }
 }
 
-hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                          int batch, size_t strideW, size_t strideH) {
     if (Kp % 64) return hipErrorInvalidValue;
     switch (Kp / 64) {
-        case 1: return launch_check_k16<1, 2>(W, H, X, Mp, Np, Kp, part, stream);
-        case 2: return launch_check_k16<2, 2>(W, H, X, Mp, Np, Kp, part, stream);
-        case 4: return launch_check_k16<4, 2>(W, H, X, Mp, Np, Kp, part, stream);
-        case 5: return launch_check_k16<5, 1>(W, H, X, Mp, Np, Kp, part, stream);
-        case 6: return launch_check_k16<6, 1>(W, H, X, Mp, Np, Kp, part, stream);
-        case 7: return launch_check_k16<7, 1>(W, H, X, Mp, Np, Kp, part, stream);
-        case 8: return launch_check_k16<8, 1>(W, H, X, Mp, Np, Kp, part, stream);
+        case 1: return launch_check_k16<1, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 2: return launch_check_k16<2, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 4: return launch_check_k16<4, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 5: return launch_check_k16<5, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 6: return launch_check_k16<6, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 7: return launch_check_k16<7, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 8: return launch_check_k16<8, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
         default: return hipErrorInvalidValue;
     }
 }

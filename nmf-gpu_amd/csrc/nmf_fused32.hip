@@ -317,8 +317,9 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a, doub
     int q0 = (qblk * 4 + wave) * 32;     // wave-uniform (SGPR)
     const bool active = q0 < Q;
     if (!active) q0 = Q - 32;
-    const float *__restrict__ V = WSTEP ? a.H : a.W;
-    const float *__restrict__ U = WSTEP ? a.W : a.H;
+    const size_t pair = CHECK ? (size_t)blockIdx.y : 0;   // the check of a batched solver: one launch over all its pairs (FusedArgs::strideW)
+    const float *__restrict__ V = (WSTEP ? a.H : a.W) + pair * (WSTEP ? a.strideH : a.strideW);
+    const float *__restrict__ U = (WSTEP ? a.W : a.H) + pair * (WSTEP ? a.strideW : a.strideH);
     const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
     const int nchunks = P / 32;
     const int cps = (nchunks + nsplit - 1) / nsplit;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_v3(FusedArgs a, doub
     }
     if (CHECK) {
         if (!active) { kl = 0.0; dabs = 0.0; xabs = 0.0; }
-        block_reduce3(kl, dabs, xabs, chk_part + 3 * (size_t)blockIdx.x, tid);
+        block_reduce3(kl, dabs, xabs, chk_part + 3 * ((size_t)blockIdx.x + pair * gridDim.x), tid);
         return;
     }
     if (!active) return;
@@ -653,12 +654,14 @@ __global__ __launch_bounds__(256, 1) void check_kernel(const float *__restrict__
 }
 
 template <int KT>
-static hipError_t launch_check_kt(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+static hipError_t launch_check_kt(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                                  int batch, size_t strideW, size_t strideH) {
     // the production half-step kernel in CHECK mode (product 1 + KL terms); NMF_FUSED_VARIANT=1 keeps the first-generation check_kernel
     if (fused_variant() != 1 && (size_t)Kp * (size_t)Mp < ((size_t)1 << 31)) {
         FusedArgs a;
         a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
         a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
+        a.strideW = strideW; a.strideH = strideH;
         const size_t lds3 = (size_t)2 * KT * 32 * kLdv * sizeof(float) + 4 * kXtFloats * sizeof(float);
         {
             hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, lds3);
@@ -666,7 +669,7 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
         }
         note_kernel((const void *)fused_step_kernel_v3<KT, false, false, 0, false, true>, stream);
 
-        hipLaunchKernelGGL((fused_step_kernel_v3<KT, false, false, 0, false, true>), dim3(check_num_groups(Np, Kp)), dim3(256), lds3, stream, a, part);
+        hipLaunchKernelGGL((fused_step_kernel_v3<KT, false, false, 0, false, true>), dim3(check_num_groups(Np, Kp), (unsigned)batch), dim3(256), lds3, stream, a, part);
         return hipGetLastError();
     }
     const size_t lds = (size_t)2 * KT * 32 * kLdv * sizeof(float);
@@ -675,17 +678,20 @@ static hipError_t launch_check_kt(const float *W, const float *H, const float *X
         if (e != hipSuccess) return e;
     }
     note_kernel((const void *)check_kernel<KT>, stream);
-
-    hipLaunchKernelGGL((check_kernel<KT>), dim3(check_num_groups(Np, Kp)), dim3(256), lds, stream, W, H, X, Mp, Np, Kp, part);
+    for (int b = 0; b < batch; ++b) {   // the first-generation check kernel takes one pair at a time
+        hipLaunchKernelGGL((check_kernel<KT>), dim3(check_num_groups(Np, Kp)), dim3(256), lds, stream, W + (size_t)b * strideW, H + (size_t)b * strideH, X, Mp, Np, Kp,
+                           part + 3 * (size_t)check_num_groups(Np, Kp) * b);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                          int batch, size_t strideW, size_t strideH) {
     switch (Kp / 32) {
-        case 1: return launch_check_kt<1>(W, H, X, Mp, Np, Kp, part, stream);
-        case 2: return launch_check_kt<2>(W, H, X, Mp, Np, Kp, part, stream);
-        case 4: return launch_check_kt<4>(W, H, X, Mp, Np, Kp, part, stream);
-        case 8: return launch_check_kt<8>(W, H, X, Mp, Np, Kp, part, stream);
+        case 1: return launch_check_kt<1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 2: return launch_check_kt<2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 4: return launch_check_kt<4>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        case 8: return launch_check_kt<8>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
         default: return hipErrorInvalidValue;
     }
 }

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -121,11 +122,7 @@ struct nmf_solver {
     unsigned *range_flag = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // check_all of a batched solver: the pairs' checks are a few workgroups each (the reference's 4096 x 350 x 128: six), so
-    // they run side by side on helper streams, forked from and joined to `stream` by events
-    static constexpr int kAux = 4;
-    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t aux_fork = nullptr, aux_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    int stream_device = -1;        // device the pooled stream belongs to
     nmf_comm *comm = nullptr;      // sharded over N with in-library RCCL all-reduce
     bool external_reduce = false;  // sharded, caller reduces the partial buffer
     bool comm_warm = false;        // one eager all-reduce has run on this communicator (before any capture)
@@ -190,6 +187,34 @@ struct Arena {
         return NMF_OK;
     }
 };
+
+// Library-owned streams are pooled per device: creating one costs 1.5-2 ms (a hardware queue behind it), which is a fifth of a
+// one-shot update_div on the reference's own problem.  A destroyed solver hands its (drained) stream back; the next solver on
+// that device takes it.  At most kStreamPool idle streams per device are kept; the rest are destroyed.
+namespace {
+constexpr int kStreamPool = 8, kPoolDevices = 64;
+std::mutex g_pool_mu;
+std::vector<hipStream_t> g_pool[kPoolDevices];
+int acquire_stream(hipStream_t *out) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < kPoolDevices) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool[dev].empty()) { *out = g_pool[dev].back(); g_pool[dev].pop_back(); return NMF_OK; }
+    }
+    HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return NMF_OK;
+}
+void release_stream(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kPoolDevices && hipStreamQuery(st) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if ((int)g_pool[dev].size() < kStreamPool) { g_pool[dev].push_back(st); return; }
+    }
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(st);
+}
+}  // namespace
 
 // launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
 constexpr int kMaxRowsApplyColsum = 65536;
@@ -304,7 +329,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     s->fast_divide = o.fast_divide;
     s->comm = (nmf_comm *)o.comm;
     if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    else { NMFCHK(acquire_stream(&s->stream)); s->own_stream = true; s->stream_device = -1; (void)hipGetDevice(&s->stream_device); }
 
     const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
     Arena ar;
@@ -361,7 +386,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         ar.reserve((void **)&s->partials, ((size_t)s->nsplit_w * mk) * sizeof(float));
         s->chk_groups = reduce_num_groups(mn);
     }
-    ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups * (size_t)batch);   // one set per pair: check_all runs the pairs' checks side by side
+    ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups * (size_t)batch);   // one set per pair: check_all evaluates every pair in one launch
     ar.reserve((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch);
     s->chk_host.assign(3 * (size_t)batch, 0.0);
     if (batch > 1) ar.reserve((void **)&s->active_d, sizeof(int) * (size_t)batch);   // from the start: captured graphs never hold a stale null pointer
@@ -369,7 +394,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     if (path == NMF_PATH_FUSED) {
         ar.reserve((void **)&s->xc_part, sizeof(double) * 3 * (size_t)kXConstGroups);
         ar.reserve((void **)&s->xc3, sizeof(double) * 3, true);
-        ar.reserve((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks) * (size_t)batch);
+        ar.reserve((void **)&s->sum64, sizeof(double) * ((size_t)s->Kp + kSum64Blocks));
     }
     s->staging_count = (size_t)M * N;
     if ((size_t)M * K > s->staging_count) s->staging_count = (size_t)M * K;
@@ -404,14 +429,15 @@ extern "C" void nmf_solver_destroy(nmf_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_graphs(s);
     for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (int i = 0; i < nmf_solver::kAux; ++i) {
-        if (s->aux[i]) (void)hipStreamDestroy(s->aux[i]);
-        if (s->aux_join[i]) (void)hipEventDestroy(s->aux_join[i]);
-    }
-    if (s->aux_fork) (void)hipEventDestroy(s->aux_fork);
     if (s->arena) (void)hipFree(s->arena);
     if (s->active_own) (void)hipFree(s->active_own);
-    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->own_stream && s->stream) {   // back to the pool of its device (drained above)
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (s->stream_device >= 0 && cur != s->stream_device) (void)hipSetDevice(s->stream_device);
+        release_stream(s->stream);
+        if (s->stream_device >= 0 && cur >= 0 && cur != s->stream_device) (void)hipSetDevice(cur);
+    }
     delete s;
 }
 
@@ -1040,31 +1066,15 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     if (s->path != NMF_PATH_FUSED) { set_err("check_all: fused path only"); return NMF_ERR_UNSUPPORTED; }
     hipStream_t st = s->stream;
     NMFCHK(ensure_x_consts(s));
-    const int nlanes = s->batch < nmf_solver::kAux ? s->batch : nmf_solver::kAux;
-    bool fork = s->batch > 1;
-    if (fork && !s->aux_fork) {   // helper streams, created at the first use
-        if (hipEventCreateWithFlags(&s->aux_fork, hipEventDisableTiming) != hipSuccess) fork = false;
-        for (int i = 0; fork && i < nmf_solver::kAux; ++i)
-            if (hipStreamCreateWithFlags(&s->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->aux_join[i], hipEventDisableTiming) != hipSuccess) fork = false;
-        if (!fork) { (void)hipGetLastError(); if (s->aux_fork) { (void)hipEventDestroy(s->aux_fork); s->aux_fork = nullptr; } }
-    }
-    if (fork) {
-        HIPCHK(hipEventRecord(s->aux_fork, st));
-        for (int i = 0; i < nlanes; ++i) HIPCHK(hipStreamWaitEvent(s->aux[i], s->aux_fork, 0));
-    }
-    const size_t part_stride = 3 * (size_t)s->chk_groups, sum_stride = (size_t)s->Kp + kSum64Blocks;
+    // ONE launch of the check kernel over all pairs (blockIdx.y): a pair's check is a few workgroups (the reference's
+    // 4096 x 350 x 128: six, ~130 us) and sixteen of them one after the other were 2.7 ms of a 60 ms call -- at every
+    // convergence check of a run with a threshold.  The fp64 composition (three small launches) stays per pair.
+    const size_t part_stride = 3 * (size_t)s->chk_groups;
+    HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st, s->batch, (size_t)s->Mp * s->Kp, (size_t)s->Kp * s->Np));
     for (int b = 0; b < s->batch; ++b) {
-        hipStream_t sb = fork ? s->aux[b % nlanes] : st;
-        double *part = s->chk_part + (fork ? (size_t)b * part_stride : 0), *sum64 = s->sum64 + (fork ? (size_t)b * sum_stride : 0);
         const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
-        HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, part, sb));
-        HIPCHK(launch_check_compose(part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, sum64, s->chk_out + 3 * (size_t)b, sb));
+        HIPCHK(launch_check_compose(s->chk_part + (size_t)b * part_stride, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
     }
-    if (fork)
-        for (int i = 0; i < nlanes; ++i) {
-            HIPCHK(hipEventRecord(s->aux_join[i], s->aux[i]));
-            HIPCHK(hipStreamWaitEvent(st, s->aux_join[i], 0));
-        }
     HIPCHK(hipMemcpyAsync(s->chk_host.data(), s->chk_out, sizeof(double) * 3 * (size_t)s->batch, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < s->batch; ++b) {
@@ -1429,9 +1439,10 @@ constexpr int kMaxRestartBatch = 64;
 static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     nmf_opts o = o_in;
-    // as in update_div_ex: a run too short does not earn back the capture and instantiation of its graphs (1-2 ms); the work of
-    // a batch counts B-fold (16 x cfg2: 319 us per iteration of the batch replayed, 332 us launched eagerly)
-    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)B * (double)o.max_iter < 2e12) ? -1 : 1;
+    // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs -- with B pairs per
+    // launch a 32-iteration graph costs ~20 ms to capture and instantiate (16 x cfg2 x 200 iterations: 72 ms launched eagerly,
+    // 93-96 ms with the B-fold flop count deciding for capture, round 3) while every launch outlasts its own enqueue by far
+    if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
     const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;   // wall time of every phase of the call, to stderr
     double tp = now_s();
     auto phase = [&](const char *what) { if (trace) { const double t = now_s(); fprintf(stderr, "nmf restarts: %-28s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };

@@ -37,6 +37,9 @@ struct FusedArgs {
     int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
     int x_in_range;           // 1: every entry of X is 0 or in [EPS, 2^60] (checked at upload): the 16-column kernel may
                               //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
+    // CHECK instantiations only: blockIdx.y = pair of a batched solver (W, H of pair b at + b * strideW / strideH floats; its
+    // partial triples behind those of pair b - 1): nmf_solver_check_all evaluates every pair's check in ONE launch
+    size_t strideW = 0, strideH = 0;
     float *vsum_part = nullptr;   // optional, W-step with partial slabs on the 16-column kernel (fused_streams_vsum()): nsplit x Kp
                               //    floats receiving, per split, the row sums of the streamed factor H over that split's columns
                               //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
@@ -51,8 +54,10 @@ hipError_t launch_check_pair(const float *W, const float *H, const float *X, int
 // C = A * B through product 1 of the 16-column kernel (the W*H shape: tall A, K <= 512), see nmf_fused16.hip
 bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
-hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
-hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
+hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                          int batch = 1, size_t strideW = 0, size_t strideH = 0);
+hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                          int batch = 1, size_t strideW = 0, size_t strideH = 0);
 #ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library
 hipError_t launch_mfma_valu_probe(int nv, int chain, float *out, int iters, hipStream_t stream);   // micro-probe
 hipError_t launch_mfma_partner_probe(int mode, float *out, int iters, hipStream_t stream);   // micro-probe 2
@@ -120,8 +125,10 @@ int        check_num_groups(int Np, int Kp);
 bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
 int        fused_pad_k(int K);             // K padded to an instantiated kernel size, 0 if the fused path cannot take it
+// batch > 1: `batch` (W, H) pairs, strideW / strideH floats apart, in one launch (grid.y); pair b's check_num_groups triples
+// at part + 3 * check_num_groups * b.  Kp <= 512 (the batched solvers' range); the wave-pair kernel takes one pair at a time.
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,
-                        double *part, hipStream_t stream);
+                        double *part, hipStream_t stream, int batch = 1, size_t strideW = 0, size_t strideH = 0);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
 constexpr int kXConstGroups = 1024;     // partial triples of launch_x_consts
 constexpr int kSum64Blocks = 2048;      // workgroup partials of the weighted fp64 sum over H

@@ -49,10 +49,18 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
     return use_k16(a.Kp) ? launch_fused16(a, wstep, stream) : launch_fused32(a, wstep, stream);
 }
 
-hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream) {
+hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+                        int batch, size_t strideW, size_t strideH) {
     if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
-    if (use_pair(Kp)) return launch_check_pair(W, H, X, Mp, Np, Kp, part, stream);
-    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, part, stream) : launch_check32(W, H, X, Mp, Np, Kp, part, stream);
+    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    if (use_pair(Kp)) {
+        for (int b = 0; b < batch; ++b) {
+            hipError_t e = launch_check_pair(W + (size_t)b * strideW, H + (size_t)b * strideH, X, Mp, Np, Kp, part + 3 * (size_t)check_num_groups(Np, Kp) * b, stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
 }
 
 // one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows

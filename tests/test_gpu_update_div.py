@@ -506,6 +506,32 @@ def test_cfg4_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, ora
     assert oracle.relF(Hm.mat[:, -ns:], Hr[:, -ns:]) < 1e-4 and oracle.relF(Hg[:, -ns:], Hr[:, -ns:]) < 1e-4
 
 
+def test_cfg5_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, oracle):
+    """BASELINE config 5 (M=8192, N=131072, R=512: the tall-skinny 8-GPU configuration; X is 4 GiB) against the oracle after
+    K_par = 2 iterations (4.4 TFLOP each on the CPU), on one GPU and as the eight column shards of 16384 the config names,
+    through the in-library driver with emulated ranks (16 MiB all-reduce operand per iteration)."""
+    import time
+    M, N, K, G, KPAR = 8192, 131072, 512, 8, 2
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    t0 = time.time()
+    Wr, Hr = oracle.update_div_fast(W, H, X, KPAR)
+    dt = time.time() - t0
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(KPAR)
+    Wg, Hg = s.download()
+    s.close()
+    e1 = (oracle.relF(Wg, Wr), oracle.relF(Hg, Hr))
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=KPAR, emulate_shards=G)
+    e8 = (oracle.relF(Wm.mat, Wr), oracle.relF(Hm.mat, Hr))
+    e18 = (oracle.relF(Wm.mat, Wg), oracle.relF(Hm.mat, Hg))
+    print(f"cfg5 K_par={KPAR} vs oracle ({dt:.0f} s of CPU): one GPU relF(W, H) = {e1[0]:.2e}, {e1[1]:.2e}; 8 emulated shards = {e8[0]:.2e}, {e8[1]:.2e}; "
+          f"one GPU vs 8 shards {e18[0]:.2e}, {e18[1]:.2e}")
+    assert r["n_shards"] == G and r["w_replicas_identical"] == 1 and r["iterations"] == KPAR
+    assert max(e1) < 1e-4 and max(e8) < 1e-4 and max(e18) < 1e-5
+
+
 def test_multi_restart_picks_lowest_kl(ng, oracle):
     """paper section 3.2 / SURVEY 8(f4): several initialisations against one resident X, best final KL wins"""
     M, N, K, R = 128, 200, 16, 4
