@@ -182,6 +182,24 @@ def test_restarts_dealt_to_several_workers_equal_the_one_device_call_bit_for_bit
     assert oracle.relF(Wg[2].mat, wr) < 2e-5 and oracle.relF(Hg[2].mat, hr) < 2e-5
 
 
+def test_more_restarts_than_one_batch_holds(ng, oracle):
+    """70 restarts: a batched solver carries at most 64 pairs, so the call makes a second pass of six with the other pairs frozen
+    (set_active); every restart against the oracle, the winner the arg-min, also when the restarts are dealt to two workers"""
+    M, N, K, R = 96, 160, 16, 70
+    X, _, _ = oracle.gen_problem(M, N, K, seed=47)
+    Ws, Hs = _pairs(M, N, K, R, 48)
+    W1, H1 = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    b1, kl1 = ng.update_div_restarts(W1, H1, ng.Matrix(X), max_iter=30, n_devices=1)
+    worst = 0.0
+    for i in range(R):
+        wr, hr, _, _ = oracle.update_div(Ws[i], Hs[i], X, 0.0, 30, 25)
+        worst = max(worst, oracle.relF(W1[i].mat, wr), oracle.relF(H1[i].mat, hr))
+    assert worst < 2e-5 and b1 == int(np.argmin(kl1))
+    W2, H2 = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    b2, kl2 = ng.update_div_restarts(W2, H2, ng.Matrix(X), max_iter=30, n_devices=2, devices=[0, 0])
+    assert b2 == b1 and kl2 == kl1 and all(np.array_equal(a.mat, b.mat) for a, b in zip(W1 + H1, W2 + H2))
+
+
 def test_restart_workers_refuse_what_they_cannot_do(ng, oracle):
     M, N, K = 128, 256, 32
     X, _, _ = oracle.gen_problem(M, N, K, seed=43)
