@@ -292,6 +292,10 @@ int  nmf_worth_sharding(int M, int N, int K, int n_devices);
 int  nmf_debug_record_kernels(int on);     /* returns the previous setting */
 const char *nmf_debug_last_kernel(void);
 
+/* what nmf_solver_create_batched(M, N, K, batch, opts) would run -- kernel family, padded shape, split counts, as
+ * nmf_solver_describe prints them -- without creating anything and without touching a device (works on a machine with no GPU) */
+int  nmf_plan_describe(int M, int N, int K, int batch, const nmf_opts *opts, char *buf, int buflen);
+
 /* device queries used by bench/tests */
 int  nmf_device_count(void);
 int  nmf_device_name(int device, char *buf, int buflen);

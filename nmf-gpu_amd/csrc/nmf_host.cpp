@@ -303,8 +303,9 @@ static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1, int
     return (nsc + scps - 1) / scps;
 }
 
-static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch, int split_batch) {
-    const double t0 = now_s();
+// Everything about a solver that follows from the shape and the options alone -- kernel family, padded dims, split counts,
+// waves per workgroup: no HIP call in here, so the decision tables can be tested on a machine without a GPU (nmf_plan_describe)
+static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, int batch, int split_batch) {
     s->M = M; s->N = N; s->K = K;
     int path = o.path;
     s->batch = batch;
@@ -327,21 +328,6 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     s->path = path;
     s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
     s->fast_divide = o.fast_divide;
-    s->comm = (nmf_comm *)o.comm;
-    if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
-    else { NMFCHK(acquire_stream(&s->stream)); s->own_stream = true; s->stream_device = -1; (void)hipGetDevice(&s->stream_device); }
-
-    const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
-    Arena ar;
-    bool zero_slabs = false;
-    ar.reserve((void **)&s->W, mk * batch * sizeof(float), true);
-    ar.reserve((void **)&s->H, kn * batch * sizeof(float), true);
-    if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
-    else ar.reserve((void **)&s->X, mn * sizeof(float), true);
-    ar.reserve((void **)&s->normW, ((size_t)s->Kp) * sizeof(float));
-    ar.reserve((void **)&s->normH, ((size_t)s->Kp) * sizeof(float));
-    ar.reserve((void **)&s->rowpart, ((size_t)row_sum_blocks(s->Np) * s->Kp) * sizeof(float));
-    ar.reserve((void **)&s->psum_owned, (mk + (size_t)s->Kp) * sizeof(float));
     if (s->split) {
         // eight waves per workgroup (two per SIMD from a single workgroup per CU) where K = 64 leaves the LDS for eight sub-images
         // (measured: 3 % on cfg2 alone, but 17 % slower than two independent four-wave workgroups per CU once a batch fills
@@ -359,12 +345,6 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         if (s->ns_h > nsc_h) s->ns_h = nsc_h;
         if (s->ns_w > nsc_w) s->ns_w = nsc_w;
         s->nsplit_h = s->ns_h; s->nsplit_w = s->ns_w;
-        size_t pc = (s->ns_w > 1 || batch == 1) ? (size_t)s->ns_w * mk : 0;   // an unbatched solver's W-step may always need slabs (sharded runs)
-        if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
-        ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
-        zero_slabs = true;   // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
-        const int nsm = s->ns_h > s->ns_w ? s->ns_h : s->ns_w;
-        ar.reserve((void **)&s->vpart, ((size_t)nsm * s->Kp * batch) * sizeof(float));
         s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else if (path == NMF_PATH_FUSED) {
         const int qg = fused_cols_per_group(s->Kp);
@@ -372,19 +352,62 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
+        s->chk_groups = check_num_groups(s->Np, s->Kp);
+    } else {
+        s->nsplit_w = 16;                                  // split-K slabs for the Z*H' GEMM
+        s->chk_groups = reduce_num_groups((size_t)s->Mp * s->Np);
+    }
+    return NMF_OK;
+}
+
+// the planning of nmf_solver_create_batched as one line (nmf_solver_describe's), without creating anything: tests of the
+// dispatch tables on machines without a GPU, and "what would run" queries
+extern "C" int nmf_plan_describe(int M, int N, int K, int batch, const nmf_opts *opts_in, char *buf, int buflen) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch < 1 || !buf || buflen <= 0) return NMF_ERR_ARG;
+    nmf_opts o;
+    if (opts_in) o = *opts_in; else nmf_default_opts(&o);
+    nmf_solver s;
+    NMFCHK(plan_solver(&s, M, N, K, o, batch, 0));
+    return nmf_solver_describe(&s, buf, buflen);
+}
+
+static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch, int split_batch) {
+    const double t0 = now_s();
+    NMFCHK(plan_solver(s, M, N, K, o, batch, split_batch));
+    const int path = s->path;
+    s->comm = (nmf_comm *)o.comm;
+    if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
+    else { NMFCHK(acquire_stream(&s->stream)); s->own_stream = true; s->stream_device = -1; (void)hipGetDevice(&s->stream_device); }
+
+    const size_t mk = (size_t)s->Mp * s->Kp, kn = (size_t)s->Kp * s->Np, mn = (size_t)s->Mp * s->Np;
+    Arena ar;
+    bool zero_slabs = false;
+    ar.reserve((void **)&s->W, mk * batch * sizeof(float), true);
+    ar.reserve((void **)&s->H, kn * batch * sizeof(float), true);
+    if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
+    else ar.reserve((void **)&s->X, mn * sizeof(float), true);
+    ar.reserve((void **)&s->normW, ((size_t)s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->normH, ((size_t)s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->rowpart, ((size_t)row_sum_blocks(s->Np) * s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->psum_owned, (mk + (size_t)s->Kp) * sizeof(float));
+    if (s->split) {
+        size_t pc = (s->ns_w > 1 || batch == 1) ? (size_t)s->ns_w * mk : 0;   // an unbatched solver's W-step may always need slabs (sharded runs)
+        if (s->ns_h > 1 && (size_t)s->ns_h * kn > pc) pc = (size_t)s->ns_h * kn;
+        ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
+        zero_slabs = true;   // rows / columns of pure zero padding get no workgroup: their slab entries are never written and must read as zero
+        const int nsm = s->ns_h > s->ns_w ? s->ns_h : s->ns_w;
+        ar.reserve((void **)&s->vpart, ((size_t)nsm * s->Kp * batch) * sizeof(float));
+    } else if (path == NMF_PATH_FUSED) {
         size_t pc = 0;
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
         if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
         ar.reserve((void **)&s->partials, (pc) * sizeof(float));
         if (s->nsplit_w > 1 && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp) * sizeof(float));
-        s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else {
         ar.reserve((void **)&s->Z, (mn) * sizeof(float));
         ar.reserve((void **)&s->WtZ, (kn) * sizeof(float));
         ar.reserve((void **)&s->ZHt, (mk) * sizeof(float));
-        s->nsplit_w = 16;                                  // split-K slabs for the Z*H' GEMM
         ar.reserve((void **)&s->partials, ((size_t)s->nsplit_w * mk) * sizeof(float));
-        s->chk_groups = reduce_num_groups(mn);
     }
     ar.reserve((void **)&s->chk_part, sizeof(double) * 3 * (size_t)s->chk_groups * (size_t)batch);   // one set per pair: check_all evaluates every pair in one launch
     ar.reserve((void **)&s->chk_out, sizeof(double) * 3 * (size_t)batch);
