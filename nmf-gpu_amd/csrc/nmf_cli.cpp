@@ -11,12 +11,16 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <vector>
 
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--X f] [--W f] [--H f] [--Wout f] [--Hout f] [--iters n] [--thresh x]\n"
             "          [--check n] [--verbose] [--timers] [--path auto|fused|unfused] [--device d]\n"
             "          [--devices n] (GPUs to shard the columns over; default: all when the problem is large enough)\n"
+            "          [--restarts r] [--seed s] (paper section 3.2: r initialisations -- the W, H files, then r - 1 random\n"
+            "           pairs from MT19937(s + i) -- against the one X; the pair with the lowest final KL divergence is written;\n"
+            "           --devices n then deals the restarts to n GPUs, no communicator involved)\n"
             "       %s generate [--M m] [--N n] [--K k] [--seed s] [--X f] [--W f] [--H f]\n"
             "       %s compare A.bin B.bin [--tol t]\n"
             "defaults follow cuda/nmf.cu:9-11,37-45: ../X.bin ../W.bin ../H.bin -> ../Wout.bin ../Hout.bin,\n"
@@ -117,6 +121,8 @@ int main(int argc, char **argv) {
     nmf_opts o;
     nmf_default_opts(&o);
     bool timers = false;
+    int restarts = 1;
+    unsigned seed = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(argv[0]); exit(2); } return argv[++i]; };
@@ -133,6 +139,8 @@ int main(int argc, char **argv) {
         else if (a == "--devices") o.n_devices = atoi(next());
         else if (a == "--emulate-shards") o.emulate_shards = atoi(next());
         else if (a == "--device") o.device = atoi(next());
+        else if (a == "--restarts") restarts = atoi(next());
+        else if (a == "--seed") seed = (unsigned)strtoul(next(), nullptr, 10);
         else if (a == "--path") {
             const std::string p = next();
             o.path = p == "fused" ? NMF_PATH_FUSED : p == "unfused" ? NMF_PATH_UNFUSED : NMF_PATH_AUTO;
@@ -147,6 +155,32 @@ int main(int argc, char **argv) {
     }
     printf("read %s [%ix%i]\nread %s [%ix%i]\nread %s [%ix%i]\n", fx.c_str(), X.dim[0], X.dim[1], fh.c_str(), H.dim[0], H.dim[1],
            fw.c_str(), W.dim[0], W.dim[1]);
+    if (restarts > 1) {   // multi-restart NMF: the given pair first, then random ones; best final KL wins (update_div_restarts)
+        std::vector<matrix> Ws((size_t)restarts), Hs((size_t)restarts);
+        Ws[0] = W; Hs[0] = H;
+        for (int r = 1; r < restarts; ++r) {
+            if ((st = nmf_create_matrix(&Ws[(size_t)r], W.dim[0], W.dim[1], 0.f)) || (st = nmf_create_matrix(&Hs[(size_t)r], H.dim[0], H.dim[1], 0.f))) return st;
+            std::mt19937 g(seed + (unsigned)r);
+            auto fill = [&](matrix &m) {
+                const size_t n = (size_t)m.dim[0] * m.dim[1];
+                for (size_t i = 0; i < n; ++i) { const unsigned a = (unsigned)g() >> 5, b = (unsigned)g() >> 6; m.mat[i] = (float)(((double)a * 67108864.0 + (double)b) / 9007199254740992.0); }
+            };
+            fill(Ws[(size_t)r]); fill(Hs[(size_t)r]);
+        }
+        int best = -1;
+        std::vector<double> kl((size_t)restarts);
+        st = update_div_restarts(Ws.data(), Hs.data(), restarts, X, &o, &best, kl.data());
+        if (st != NMF_OK) { fprintf(stderr, "nmf: update_div_restarts failed: %s (%s)\n", nmf_status_string(st), nmf_last_error()); return st; }
+        for (int r = 0; r < restarts; ++r) printf("restart %d: kl-divergence %.9e%s\n", r, kl[(size_t)r], r == best ? "  <- best" : "");
+        if ((st = nmf_write_matrix(Ws[(size_t)best], fwo.c_str())) || (st = nmf_write_matrix(Hs[(size_t)best], fho.c_str()))) {
+            fprintf(stderr, "nmf: %s (%s)\n", nmf_status_string(st), nmf_last_error());
+            return st;
+        }
+        printf("write %s [%ix%i]\nwrite %s [%ix%i]\n", fwo.c_str(), W.dim[0], W.dim[1], fho.c_str(), H.dim[0], H.dim[1]);
+        for (int r = 0; r < restarts; ++r) { nmf_destroy_matrix(&Ws[(size_t)r]); nmf_destroy_matrix(&Hs[(size_t)r]); }
+        nmf_destroy_matrix(&X);
+        return 0;
+    }
     nmf_result res;
     st = update_div_ex(W, H, X, &o, &res);
     if (st != NMF_OK) {

@@ -175,3 +175,25 @@ def test_multi_device_driver_over_real_rccl_with_the_one_device_of_the_box(ng, o
     assert r["n_shards"] == 1 and r["w_replicas_identical"] == 1 and r["iterations"] == 40 and len(r["kl"]) == 3
     Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 40, 20)
     assert oracle.relF(Wm.mat, Wr) < 1e-5 and oracle.relF(Hm.mat, Hr) < 1e-5 and np.allclose(r["kl"], klr, rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_cli_restarts_writes_the_best_of_r_initialisations(oracle, tmp_path):
+    """`nmf --restarts r` (paper section 3.2 through the CLI): the W, H files are restart 0, r - 1 more pairs come from
+    MT19937(seed + i); the pair with the lowest final KL is written.  Restart 0 must be what the plain run of the same files
+    gives (to the batched split's summation order), and the written pair must be the arg-min of the printed KLs."""
+    assert _run("generate", "--M", "512", "--N", "350", "--K", "64", cwd=tmp_path).returncode == 0
+    r = _run("--X", "X.bin", "--W", "W.bin", "--H", "H.bin", "--Wout", "Wb.bin", "--Hout", "Hb.bin", "--iters", "60", "--restarts", "5", "--seed", "3", cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    kls = [float(l.split()[3]) for l in r.stdout.split("\n") if l.startswith("restart ")]
+    best = [i for i, l in enumerate(l for l in r.stdout.split("\n") if l.startswith("restart ")) if "<- best" in l]
+    assert len(kls) == 5 and best == [int(np.argmin(kls))]
+    X, W, H = (oracle.read_bin(str(tmp_path / f)) for f in ("X.bin", "W.bin", "H.bin"))
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 60, 25)
+    kl0 = oracle.kl_div(oracle.clamp(X), oracle.clamp(oracle.sgemm("nn", Wr, Hr)))
+    assert abs(kls[0] - kl0) <= 1e-4 * kl0
+    Wb, Hb = oracle.read_bin(str(tmp_path / "Wb.bin")), oracle.read_bin(str(tmp_path / "Hb.bin"))
+    klb = oracle.kl_div(oracle.clamp(X), oracle.clamp(oracle.sgemm("nn", Wb, Hb)))
+    assert abs(klb - min(kls)) <= 1e-4 * klb
+    if best == [0]:
+        assert oracle.relF(Wb, Wr) < 1e-4
