@@ -102,6 +102,8 @@ struct EmuGroup {
         if (aborted) return false;
         const unsigned long gen = generation;
         if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else if (getenv("NMF_FAULT_BLOCKING_COLLECTIVE")) cv.wait(lk, [&] { return generation != gen || aborted; });   // fault injection: no deadline
+        // of its own, like a host call that blocks inside RCCL: only the watchdog of nmf_update_div_multi ends it
         else if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || aborted; })) {
             fprintf(stderr, "nmf_comm: a rank of the emulated group did not reach its collective within %.1f s; aborting the group\n", timeout_s);
             aborted = true;
@@ -130,6 +132,7 @@ struct nmf_comm {
     std::shared_ptr<EmuGroup> emu;   // set: a same-device emulated group instead of an RCCL communicator
     std::shared_ptr<RcclGroup> grp;  // set: one of the communicators of an ncclCommInitAll group
     std::atomic<bool> aborted{false};
+    std::atomic<long> beat{0};       // nmf_comm_heartbeat
     // fault injection for the tests (NMF_FAULT_ALLREDUCE=<rank>:<call>): that f32 all-reduce call of that rank fails
     long calls = 0, fail_at = 0;
 };
@@ -254,6 +257,7 @@ void nmf_comm_abort(nmf_comm *c) {
     }
     if (c->comm) { (void)g_api.CommAbort(c->comm); c->comm = nullptr; }
 }
+long nmf_comm_heartbeat(const nmf_comm *c) { return c ? c->beat.load(std::memory_order_relaxed) : 0; }
 bool nmf_comm_aborted(const nmf_comm *c) {
     if (!c) return false;
     if (c->aborted) return true;
@@ -266,6 +270,7 @@ int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char 
     const auto t0 = std::chrono::steady_clock::now();
     bool expired = false;
     for (int spins = 0;; ++spins) {
+        c->beat.fetch_add(1, std::memory_order_relaxed);
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) return nmf_comm_aborted(c) ? NMF_ERR_COMM : NMF_OK;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); return NMF_ERR_HIP; }
@@ -313,7 +318,14 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
 int nmf_comm_rank(const nmf_comm *c) { return c ? c->rank : 0; }
 int nmf_comm_size(const nmf_comm *c) { return c ? c->nranks : 1; }
 
+static int allreduce_impl(nmf_comm *c, void *buf, size_t count, ncclDataType_t dtype, hipStream_t stream);
 static int allreduce(nmf_comm *c, void *buf, size_t count, ncclDataType_t dtype, hipStream_t stream) {
+    if (c) c->beat.fetch_add(1, std::memory_order_relaxed);
+    const int st = allreduce_impl(c, buf, count, dtype, stream);
+    if (c) c->beat.fetch_add(1, std::memory_order_relaxed);
+    return st;
+}
+static int allreduce_impl(nmf_comm *c, void *buf, size_t count, ncclDataType_t dtype, hipStream_t stream) {
     if (c && dtype == ncclFloat32 && c->fail_at > 0 && ++c->calls == c->fail_at) {
         fprintf(stderr, "nmf_comm: rank %d: injected all-reduce failure (NMF_FAULT_ALLREDUCE)\n", c->rank);
         return NMF_ERR_COMM;

@@ -29,5 +29,11 @@ double nmf_comm_timeout_s();
 // few seconds to drain its now-aborted collective, and return NMF_ERR_COMM.  c == nullptr: plain hipStreamSynchronize.
 int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char *what);
 
+// Liveness of a rank's host thread: bumped on entry to and return from every collective call and on every poll of
+// nmf_comm_wait.  A rank whose value stops changing is blocked inside a host call (RCCL connects its transports inside the
+// first collective's enqueue and waits there for its peers): only another thread can help it, by aborting the group --
+// nmf_update_div_multi's calling thread watches the ranks for that (nmf_multi.cpp).
+long nmf_comm_heartbeat(const nmf_comm *c);
+
 // the calling thread's nmf_last_error() text (rank threads hand their message to the thread that called update_div_ex)
 void nmf_internal_set_error(const char *msg);

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -75,6 +76,9 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
     if (cst != NMF_OK) return cst;
     std::vector<Rank> rank((size_t)G);
     std::vector<std::thread> th;
+    // 0 = setting up (uploads: no collective can block yet), 1 = in the loop (watched), 2 = finished
+    std::vector<std::atomic<int>> phase((size_t)G);
+    for (auto &p : phase) p = 0;
     int stall_rank = -1;
     if (const char *e = getenv("NMF_FAULT_STALL_RANK")) stall_rank = atoi(e);
     SetupGate gate(G);
@@ -103,7 +107,9 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             if (st == NMF_OK) st = nmf_solver_sync(s);
             r.res.t[NMF_T_H2D] = now_s() - t0;
             if (st != NMF_OK) fail(st);
+            struct Done { std::atomic<int> &p; ~Done() { p = 2; } } done_guard{phase[(size_t)g]};
             if (!gate.pass(st == NMF_OK)) { if (s) nmf_solver_destroy(s); if (r.status == NMF_OK) { r.status = NMF_ERR_COMM; snprintf(r.err, sizeof r.err, "rank %d: another rank failed during set-up", g); } return; }
+            phase[(size_t)g] = 1;
             if (stall_rank == g) {   // fault injection (NMF_FAULT_STALL_RANK): this rank never reaches its first collective
                 const double t_s = now_s();
                 while (!nmf_comm_aborted(comm[(size_t)g]) && now_s() - t_s < 20.0 * nmf_comm_timeout_s()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
@@ -117,6 +123,7 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             const double t1 = now_s();
             r.w_copy.resize((size_t)M * K);
             r.h_copy.resize((size_t)K * count[(size_t)g]);
+            phase[(size_t)g] = 2;   // no collective from here on
             st = nmf_solver_download(s, r.w_copy.data(), r.h_copy.data());
             const double h2d = r.res.t[NMF_T_H2D];
             r.res = rr;
@@ -125,6 +132,33 @@ int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const 
             if (st != NMF_OK) fail(st);
             nmf_solver_destroy(s);
         });
+    }
+    // The calling thread is the watchdog.  A rank's own waits carry deadlines (nmf_comm_wait, the emulated rendezvous), but a
+    // rank blocked INSIDE a host call -- RCCL connects transports inside the first collective's enqueue and waits there for
+    // its peers -- can be freed only from another thread: if a rank in the loop shows no sign of life (nmf_comm_heartbeat)
+    // for three time-outs, abort the group; every blocked call then returns an error and the threads end.
+    {
+        std::vector<long> last((size_t)G, -1);
+        std::vector<double> since((size_t)G, now_s());
+        const double limit = 3.0 * nmf_comm_timeout_s();
+        bool fired = false;
+        for (;;) {
+            bool all_done = true;
+            for (int g = 0; g < G; ++g) {
+                const int ph = phase[(size_t)g].load();
+                if (ph != 2) all_done = false;
+                if (ph != 1 || fired) { since[(size_t)g] = now_s(); continue; }
+                const long b = nmf_comm_heartbeat(comm[(size_t)g]);
+                if (b != last[(size_t)g]) { last[(size_t)g] = b; since[(size_t)g] = now_s(); }
+                else if (now_s() - since[(size_t)g] > limit) {
+                    fprintf(stderr, "nmf: rank %d has not moved for %.0f s (blocked inside a collective?); aborting the communicator group\n", g, limit);
+                    nmf_comm_abort(comm[(size_t)g]);
+                    fired = true;
+                }
+            }
+            if (all_done) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(fired ? 5 : 20));
+        }
     }
     for (auto &t : th) t.join();
     for (int g = 0; g < G; ++g) nmf_comm_destroy(comm[(size_t)g]);

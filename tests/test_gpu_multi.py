@@ -63,6 +63,24 @@ def test_a_rank_that_never_reaches_its_first_collective_aborts_the_group_within_
     assert np.array_equal(Wm.mat, W) and np.array_equal(Hm.mat, H)
 
 
+def test_a_rank_blocked_inside_a_host_call_is_freed_by_the_watchdog(ng, oracle, capfd):
+    """RCCL connects its transports inside the first collective's ENQUEUE and waits there for its peers: a rank blocked like
+    that never reaches the deadline of its own wait.  NMF_FAULT_BLOCKING_COLLECTIVE takes the deadline off the emulated
+    rendezvous (rank 0 blocks in it as in such a host call) while rank 1 never arrives: only the calling thread's watchdog
+    (three time-outs without a heartbeat from a rank in the loop) can abort the group.  NMF_ERR_COMM, factors untouched."""
+    M, N, K = 256, 1024, 64
+    X, W, H = oracle.gen_problem(M, N, K, seed=38)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    t0 = time.time()
+    with _env(NMF_FAULT_BLOCKING_COLLECTIVE=1, NMF_FAULT_STALL_RANK=1, NMF_COMM_TIMEOUT_S=1):
+        with pytest.raises(ng.NmfError) as e:
+            ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=20, emulate_shards=2)
+    dt = time.time() - t0
+    assert e.value.status == 6 and 2.5 < dt < 30, dt
+    assert "has not moved" in capfd.readouterr().err
+    assert np.array_equal(Wm.mat, W) and np.array_equal(Hm.mat, H)
+
+
 def test_automatic_sharding_falls_back_to_one_gpu_in_the_same_process(ng, oracle, capfd):
     """the same stall when sharding was the library's own idea (n_devices = 0; NMF_EMULATE_SHARDS stands in for the devices of
     a multi-GPU node): the drop-in call must not hang and must not fail -- it reports the aborted sharded run on stderr and
