@@ -1462,9 +1462,9 @@ constexpr int kMaxRestartBatch = 64;
 static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     nmf_opts o = o_in;
-    // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs -- with B pairs per
-    // launch a 32-iteration graph costs ~20 ms to capture and instantiate (16 x cfg2 x 200 iterations: 72 ms launched eagerly,
-    // 93-96 ms with the B-fold flop count deciding for capture, round 3) while every launch outlasts its own enqueue by far
+    // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
+    // batch outlasts its own enqueue by far): 16 restarts x 200 iterations, whole call, eager / captured: cfg2 69.5-70.3 /
+    // 70.4-71.0 ms, gold 56.9-59.0 / 58.9-59.1, paper 21.1 / 22.9-23.1 (tools/restart_graph_ab.py, round 3)
     if (o.use_graph == NMF_GRAPH_AUTO) o.use_graph = (8.0 * M * N * K * (double)o.max_iter < 2e12) ? -1 : 1;
     const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;   // wall time of every phase of the call, to stderr
     double tp = now_s();
