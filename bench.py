@@ -178,37 +178,12 @@ def main():
     shard = None
     comm_used = args.comm
     if sharded and args.comm in ("auto", "rccl"):
-        # Every rank runs the same sequence of torch collectives on both the success and the failure path: rank 0 ALWAYS
-        # broadcasts (a zeroed id when it could not make one) and an ok flag is MIN-reduced after each stage, so a rank that
-        # fails early never leaves the others waiting in a different collective.
-        def all_ok(ok):
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return int(flag.item()) == 1
-        why = ""
-        uid = torch.zeros(128, dtype=torch.uint8)
-        ok = True
-        if rank == 0:
-            try:
-                uid = torch.frombuffer(bytearray(ng.Comm.unique_id()), dtype=torch.uint8).clone()
-            except Exception as e:      # no librccl, wrong major version, ...
-                ok, why = False, str(e)
-        uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        ok = all_ok(ok)
-        if ok:
-            try:
-                comm = ng.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            except Exception as e:      # ncclCommInitRank failure (e.g. two ranks on one device)
-                ok, why = False, str(e)
-            ok = all_ok(ok)
-        if not ok:
+        # every rank runs the same torch collectives on the success and the failure path (nmf_gpu_amd.sharded.negotiate_comm)
+        comm, why = ng.negotiate_comm(dist, torch, rank, world, ng.Comm.unique_id, ng.Comm, device="cuda")
+        if comm is None:
             if args.comm == "rccl":
-                raise SystemExit(f"bench.py rank {rank}: --comm rccl: the in-library RCCL communicator could not be set up on every rank ({why or 'another rank failed'})")
-            print(f"bench.py rank {rank}: in-library RCCL unavailable ({why or 'another rank failed'}); using torch.distributed", file=sys.stderr)
-            if comm is not None:
-                comm.close()
-            comm = None
+                raise SystemExit(f"bench.py rank {rank}: --comm rccl: the in-library RCCL communicator could not be set up on every rank ({why})")
+            print(f"bench.py rank {rank}: in-library RCCL unavailable ({why}); using torch.distributed", file=sys.stderr)
             comm_used = "torch"
         else:
             comm_used = "rccl"

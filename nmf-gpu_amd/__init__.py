@@ -8,4 +8,4 @@ fallback: importing :mod:`nmf_gpu_amd.api` raises if the HIP library has not bee
 """
 from .api import *  # noqa: F401,F403
 from .api import __all__  # noqa: F401
-from .sharded import ShardedLoop, GpuShard, column_shards, worth_sharding  # noqa: F401,E402
+from .sharded import ShardedLoop, GpuShard, column_shards, worth_sharding, negotiate_comm  # noqa: F401,E402

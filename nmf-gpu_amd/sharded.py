@@ -45,6 +45,42 @@ def worth_sharding(M: int, N: int, K: int, world: int) -> bool:
     return compute_s >= 4.0 * comm_s
 
 
+def negotiate_comm(dist, torch, rank: int, world: int, unique_id: Callable, make_comm: Callable, device: str = "cuda"):
+    """Set up one in-library communicator per rank -- rank 0 makes the 128-byte id (``unique_id()``), torch broadcasts it,
+    every rank calls ``make_comm(id_bytes, rank, world)`` -- such that EVERY rank runs the same sequence of torch collectives
+    whether or not something fails: rank 0 always broadcasts (a zeroed id when it could not make one) and an ok flag is
+    MIN-reduced after each stage, so a rank that fails early never leaves the others waiting in a different collective
+    (round-2 advisor: a rank raising before the broadcast deadlocked the rest until the process-group time-out).
+    Returns (comm, "") on every rank, or (None, reason) on every rank; a communicator made by a rank whose peers failed is
+    closed before returning."""
+    def all_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    why, comm, ok = "", None, True
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        try:
+            uid = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).clone()
+        except Exception as e:      # no librccl, wrong major version, ...
+            ok, why = False, str(e)
+    uid = uid.to(device)
+    dist.broadcast(uid, 0)
+    ok = all_ok(ok)
+    if ok:
+        try:
+            comm = make_comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as e:      # ncclCommInitRank failure (e.g. two ranks on one device)
+            ok, why = False, str(e)
+        ok = all_ok(ok)
+    if not ok:
+        if comm is not None:
+            comm.close()
+        return None, why or "another rank failed"
+    return comm, ""
+
+
 class ShardedLoop:
     """The update_div loop of one rank (README.md:40-54 contract; checks are summed over ranks)."""
 

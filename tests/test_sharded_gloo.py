@@ -109,3 +109,59 @@ def test_sharded_loop_matches_single_process(oracle, world, N):
         assert np.array_equal(w, Ws[0])            # W replicated bit for bit
     assert oracle.relF(Ws[0], Wr) < 1e-5 and oracle.relF(Hcat, Hr) < 1e-5
     assert np.allclose(kls, klr, rtol=1e-6)
+
+
+def _negotiate_worker(rank, world, port, fail, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import nmf_gpu_amd as ng
+    from datetime import timedelta
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    closed = []
+
+    class FakeComm:
+        def __init__(self, uid, r, w):
+            if fail == ("comm", r):
+                raise RuntimeError("ncclCommInitRank failed")
+            self.uid, self.rank = uid, r
+
+        def close(self):
+            closed.append(self.rank)
+
+    def unique_id():
+        if fail == ("uid", 0):
+            raise RuntimeError("librccl not loadable")
+        return bytes(range(128))
+
+    comm, why = ng.negotiate_comm(dist, torch, rank, world, unique_id, FakeComm, device="cpu")
+    dist.barrier()                       # everybody got here: nobody is stuck in a collective the others never entered
+    q.put((rank, comm is not None, comm.uid == bytes(range(128)) if comm is not None else None, why, closed))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [None, ("uid", 0), ("comm", 1), ("comm", 0)])
+def test_comm_negotiation_runs_the_same_collectives_on_every_rank_whatever_fails(fail):
+    """bench.py's RCCL-or-torch decision (nmf_gpu_amd.sharded.negotiate_comm) over gloo with three ranks and a fake
+    communicator: rank 0 failing to make the id, or any rank failing to build its communicator, must leave EVERY rank with
+    'no communicator' (and close the ones that were built) instead of a rank waiting in a broadcast the failing rank never
+    entered (round-2 advisor)."""
+    import multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, world, port, fail, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if fail is None:
+        assert all(ok and same_uid and why == "" for _, ok, same_uid, why, _ in out)
+    else:
+        assert all(not ok and why for _, ok, _, why, _ in out)
+        if fail[0] == "comm":            # the ranks that did build one closed it
+            assert all(closed == ([r] if r != fail[1] else []) for r, _, _, _, closed in out)
