@@ -263,7 +263,8 @@ void *nmf_solver_stream(nmf_solver *s);
  * Several GPUs ("replicas only", below the size where sharding ONE problem pays): restart i runs on worker i % G, one host
  * thread + one batched solver + one copy of X per worker, no communicator and no collective.  opts->n_devices = G > 1
  * (optionally with opts->devices, which may name a device more than once) forces G workers; 0 = automatic: every visible
- * device unless opts->device pins one (NMF_DEVICES=<n>|all overrides); 1 = one device.  Needs X.mat (host).  Every restart
+ * device when the call holds at least ~0.5 s of single-GPU work (5e13 flop; bringing up a device costs a few hundred
+ * milliseconds), unless opts->device pins one (NMF_DEVICES=<n>|all overrides either way); 1 = one device.  Needs X.mat (host).  Every restart
  * gets the same kernels and split counts wherever it runs: its result is bit-identical to the one-device call's.
  * ------------------------------------------------------------------------------------- */
 int  update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts,

@@ -1576,7 +1576,7 @@ static int restarts_one_device(const matrix *W, const matrix *H, int n_restarts,
 // nmf_opts.n_devices = n > 1 (with an optional `devices` list, which may name a device more than once: each entry is a worker
 // with its own solver and stream) forces; 0 = automatic: every visible device unless the caller pinned one (device >= 0) or
 // NMF_DEVICES=<n>|all says otherwise; 1 = the one device.
-static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x, std::vector<int> &devices) {
+static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x, double flop, std::vector<int> &devices) {
     devices.clear();
     if (o.comm || o.stream || !host_x || n_restarts < 2) return;
     int want = o.n_devices;
@@ -1586,6 +1586,9 @@ static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x,
     if (want == 0) {
         if (o.device >= 0 && !o.devices) return;
         const char *e = getenv("NMF_DEVICES");
+        // by itself the library spreads only work worth it: bringing up a device this process has not used yet costs a few
+        // hundred milliseconds, so below ~0.5 s of single-GPU work (5e13 flop) the restarts stay on one device
+        if (!(e && e[0]) && flop < 5e13) return;
         want = (e && e[0]) ? ((strcmp(e, "all") == 0) ? ndev : atoi(e)) : ndev;
         if (want > ndev) want = ndev;
     }
@@ -1614,7 +1617,7 @@ extern "C" int update_div_restarts(const matrix *W, const matrix *H, int n_resta
     if (o.n_devices > 1 && (o.comm || o.stream || !X.mat)) { set_err("update_div_restarts: n_devices > 1 needs a host X and no caller stream or communicator"); return NMF_ERR_ARG; }
     const int split_batch = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     std::vector<int> devices;
-    plan_restart_devices(o, n_restarts, X.mat != nullptr, devices);
+    plan_restart_devices(o, n_restarts, X.mat != nullptr, 8.0 * M * N * K * (double)o.max_iter * n_restarts, devices);
     if (o.n_devices > 1 && devices.empty() && n_restarts > 1) { set_err("update_div_restarts: n_devices = %d: not that many devices visible", o.n_devices); return NMF_ERR_ARG; }
     if (devices.empty()) return restarts_one_device(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch);
 
