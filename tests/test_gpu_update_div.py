@@ -314,6 +314,34 @@ def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
     assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
 
 
+@pytest.mark.parametrize("M,N,K,kw", [(96, 65536, 16, {}), (128, 65536, 64, {"split_kernel": -1}), (128, 32768, 64, {"split_kernel": 1})])
+def test_gpu_against_an_fp64_evaluation_over_long_reductions(ng, M, N, K, kw):
+    """The GPU against float64 numpy directly (no oracle in between), on shapes whose W-step sums 32768-65536 columns: 20
+    iterations, relF <= 2e-5, and no common scale factor between the factors (|scale| < 2e-6) -- the signature of a biased
+    long reduction, which is what the first cfg3 x 200 comparison exposed in the oracle's fast arrangement (round 3)."""
+    rng = np.random.default_rng(7)
+    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    eps, iters = float(ng.EPS), 20
+    W64, H64, X64 = np.maximum(W.astype(np.float64), eps), np.maximum(H.astype(np.float64), eps), np.maximum(X.astype(np.float64), eps)
+    for _ in range(iters):
+        Z = X64 / np.maximum(W64 @ H64, eps)
+        H64 = H64 * ((W64.T @ Z) / np.maximum(W64.sum(0), eps)[:, None])
+        Z = X64 / np.maximum(W64 @ H64, eps)
+        W64 = W64 * ((Z @ H64.T) / np.maximum(H64.sum(1), eps)[None, :])
+    s = ng.Solver(M, N, K, **kw)
+    s.upload(W, H, X)
+    s.iterate(iters)
+    Wg, Hg = s.download()
+    d = s.describe()
+    s.close()
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    scale = float(np.vdot(Wg.astype(np.float64), W64) / np.vdot(W64, W64)) - 1.0
+    print(f"{d}: vs fp64 after {iters} iterations relF(W) = {rel(Wg, W64):.2e}, relF(H) = {rel(Hg, H64):.2e}, scale of W {scale:+.1e}")
+    assert rel(Wg, W64) < 2e-5 and rel(Hg, H64) < 2e-5 and abs(scale) < 2e-6
+
+
 def test_cfg3_200_iterations_kl_monotone(ng):
     """SURVEY 8(d) gate for the shapes the CPU cannot iterate 200 times: the full 200-iteration run at
     BASELINE config 3, KL checked every 25 iterations, must decrease at every check and stay finite."""
