@@ -342,6 +342,35 @@ def test_gpu_against_an_fp64_evaluation_over_long_reductions(ng, M, N, K, kw):
     assert rel(Wg, W64) < 2e-5 and rel(Hg, H64) < 2e-5 and abs(scale) < 2e-6
 
 
+def test_cfg3_against_an_fp64_evaluation(ng, oracle):
+    """BASELINE config 3 at full size against float64 numpy directly (no oracle in between), 10 iterations from the seed-0
+    inputs: closes the chain GPU ~ oracle (200 iterations, previous test) and oracle ~ fp64 (tests/test_oracle_ops.py) at the
+    headline shape itself.  ~1 TFLOP of fp64 BLAS per iteration on the host."""
+    import time
+    M, N, K, iters = 4096, 65536, 256, 10
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    s = ng.Solver(M, N, K)
+    s.upload(W, H, X)
+    s.iterate(iters)
+    Wg, Hg = s.download()
+    s.close()
+    eps = float(ng.EPS)
+    t0 = time.time()
+    W64, H64, X64 = np.maximum(W.astype(np.float64), eps), np.maximum(H.astype(np.float64), eps), np.maximum(X.astype(np.float64), eps)
+    Z = np.empty_like(X64)
+    for _ in range(iters):
+        np.matmul(W64, H64, out=Z); np.maximum(Z, eps, out=Z); np.divide(X64, Z, out=Z)
+        H64 *= (W64.T @ Z) / np.maximum(W64.sum(0), eps)[:, None]
+        np.matmul(W64, H64, out=Z); np.maximum(Z, eps, out=Z); np.divide(X64, Z, out=Z)
+        W64 *= (Z @ H64.T) / np.maximum(H64.sum(1), eps)[None, :]
+    dt = time.time() - t0
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    scale = float(np.vdot(Wg.astype(np.float64), W64) / np.vdot(W64, W64)) - 1.0
+    eW, eH = rel(Wg, W64), rel(Hg, H64)
+    print(f"cfg3 vs fp64 numpy after {iters} iterations ({dt:.0f} s of CPU): relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, scale of W {scale:+.1e}")
+    assert eW < 1e-5 and eH < 1e-5 and abs(scale) < 2e-6
+
+
 def test_cfg3_200_iterations_kl_monotone(ng):
     """SURVEY 8(d) gate for the shapes the CPU cannot iterate 200 times: the full 200-iteration run at
     BASELINE config 3, KL checked every 25 iterations, must decrease at every check and stay finite."""
