@@ -342,6 +342,26 @@ def test_gpu_against_an_fp64_evaluation_over_long_reductions(ng, M, N, K, kw):
     assert rel(Wg, W64) < 2e-5 and rel(Hg, H64) < 2e-5 and abs(scale) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)])
+def test_small_shapes_200_iterations_against_fp64(ng, oracle, M, N, K):
+    """BASELINE config 2, the reference's own problem (matrix_export.py:4-7) and the paper's example: the reference's 200
+    iterations (cuda/nmf.cu:10) on the default path against float64 numpy directly; north_star's bound 1e-4, measured ~1e-6-1e-5."""
+    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    eps, iters = float(ng.EPS), 200
+    W64, H64, X64 = np.maximum(W.astype(np.float64), eps), np.maximum(H.astype(np.float64), eps), np.maximum(X.astype(np.float64), eps)
+    for _ in range(iters):
+        Z = X64 / np.maximum(W64 @ H64, eps)
+        H64 = H64 * ((W64.T @ Z) / np.maximum(W64.sum(0), eps)[:, None])
+        Z = X64 / np.maximum(W64 @ H64, eps)
+        W64 = W64 * ((Z @ H64.T) / np.maximum(H64.sum(1), eps)[None, :])
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, iters, None, 0)          # the documented drop-in call
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    eW, eH, eWH = rel(Wm.mat, W64), rel(Hm.mat, H64), rel(Wm.mat.astype(np.float64) @ Hm.mat.astype(np.float64), W64 @ H64)
+    print(f"{M}x{N}x{K} x {iters} iterations, update_div vs float64 numpy: relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, relF(W*H) = {eWH:.2e}")
+    assert eW < 1e-4 and eH < 1e-4 and eWH < 1e-4
+
+
 def test_cfg3_against_an_fp64_evaluation(ng, oracle):
     """BASELINE config 3 at full size against float64 numpy directly (no oracle in between), 10 iterations from the seed-0
     inputs: closes the chain GPU ~ oracle (200 iterations, previous test) and oracle ~ fp64 (tests/test_oracle_ops.py) at the
