@@ -348,12 +348,14 @@ def test_small_shapes_200_iterations_against_fp64(ng, oracle, M, N, K):
     iterations (cuda/nmf.cu:10) on the default path against float64 numpy directly; north_star's bound 1e-4, measured ~1e-6-1e-5."""
     X, W, H = oracle.gen_problem(M, N, K, seed=0)
     eps, iters = float(ng.EPS), 200
-    W64, H64, X64 = np.maximum(W.astype(np.float64), eps), np.maximum(H.astype(np.float64), eps), np.maximum(X.astype(np.float64), eps)
+    # C-ordered float64 copies, every temporary preallocated: 200 iterations of numpy elementwise passes are what this test costs
+    W64, H64, X64 = (np.ascontiguousarray(np.maximum(a.astype(np.float64), eps)) for a in (W, H, X))
+    Z = np.empty_like(X64)
     for _ in range(iters):
-        Z = X64 / np.maximum(W64 @ H64, eps)
-        H64 = H64 * ((W64.T @ Z) / np.maximum(W64.sum(0), eps)[:, None])
-        Z = X64 / np.maximum(W64 @ H64, eps)
-        W64 = W64 * ((Z @ H64.T) / np.maximum(H64.sum(1), eps)[None, :])
+        np.matmul(W64, H64, out=Z); np.maximum(Z, eps, out=Z); np.divide(X64, Z, out=Z)
+        H64 *= (W64.T @ Z) / np.maximum(W64.sum(0), eps)[:, None]
+        np.matmul(W64, H64, out=Z); np.maximum(Z, eps, out=Z); np.divide(X64, Z, out=Z)
+        W64 *= (Z @ H64.T) / np.maximum(H64.sum(1), eps)[None, :]
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)
     ng.update_div(Wm, Hm, ng.Matrix(X), 0.0, iters, None, 0)          # the documented drop-in call
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
