@@ -30,12 +30,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz
-# PMC numbers are NOT measured by this script (counters need rocprofv3 passes of their own): the block below is copied from
-# the committed profile of this command and is reported under "pmc_static" with its source, never mixed into live values.
-PMC_STATIC = {(4096, 65536, 256): {
-    "source": "profiles/r03_pmc_summary.md: rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (not this run)",
-    "hbm_bytes_per_launch": {"H": 1.369e9, "W": 1.208e9}, "algorithmic_bytes_per_launch": 1.21e9,
-    "mfma_busy_frac_of_simd_cycles": {"H": 0.910, "W": 0.917}}}
+# HBM traffic is a PMC quantity (rocprofv3 --pmc passes of their own, collected and corrected as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE doubled on gfx950): this script does not collect counters.  `roofline.traffic` is the bytes per launch of the dominant
+# kernel from the committed PMC passes of this very command (profiles/pmc_static.json, written by tools/pmc_summary.py --json),
+# reported with its source; dividing it by THIS run's ms_per_launch gives `hbm_tbps` next to `algorithmic_tbps`.
+def pmc_static(M, N, K):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_static.json")) as f:
+            return json.load(f).get(f"{M}x{N}x{K}")
+    except Exception:
+        return None
+
+
+# X once + the owned factor in and out + the streamed factor once (it is re-read from L2): algorithmic bytes of one half-step
+def algorithmic_bytes(M, N, K):
+    return 4.0 * (M * N + 2.0 * K * N + M * K), 4.0 * (M * N + 2.0 * M * K + K * N)   # H-step, W-step
 
 
 def _draw(rs, rows, cols, keep=True):
@@ -104,9 +113,10 @@ def main():
     ap.add_argument("--N", type=int, default=65536, help="columns PER GPU")
     ap.add_argument("--K", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
-    ap.add_argument("--preset", choices=["cfg3", "cfg2", "gold", "paper", "cfg4", "cfg5"], default="cfg3",
+    ap.add_argument("--preset", choices=["cfg3", "cfg2", "gold", "gold100", "gold200", "paper", "cfg4", "cfg5"], default="cfg3",
                     help="cfg3 (default, BASELINE config 3: the metric's configuration); cfg2 = 1024 x 4096 x 64 (BASELINE config 2), gold = the "
-                         "reference's own 4096 x 350 x 128 (matrix_export.py:4-7), paper = 512 x 3445 x 30: the same JSON line for the small shapes; "
+                         "reference's own 4096 x 350 x 128 (matrix_export.py:4-7; gold100 / gold200: the same problem at R = 100 / 200, ranks between the "
+                         "powers of two), paper = 512 x 3445 x 30: the same JSON line for the small shapes; "
                          "cfg4 = 4096 x 262144 x 256 and cfg5 = 8192 x 131072 x 512 (BASELINE configs 4, 5): strong scaling, the columns split over --gpus")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="N>1: all-reduce by in-library RCCL captured inside the per-iteration hipGraph (rccl; auto = rccl, falling "
@@ -128,7 +138,8 @@ def main():
         args.M, args.strong_total_N, args.K = {"cfg4": (4096, 262144, 256), "cfg5": (8192, 131072, 512)}[args.preset]
         args.N = args.strong_total_N
     elif args.preset != "cfg3":
-        args.M, args.N, args.K = {"cfg2": (1024, 4096, 64), "gold": (4096, 350, 128), "paper": (512, 3445, 30)}[args.preset]
+        args.M, args.N, args.K = {"cfg2": (1024, 4096, 64), "gold": (4096, 350, 128), "gold100": (4096, 350, 100), "gold200": (4096, 350, 200),
+                                  "paper": (512, 3445, 30)}[args.preset]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -260,6 +271,10 @@ def main():
     ms_k = max(ms_h, ms_w)
     k_flops = 4.0 * M * Nloc * K
     achieved = k_flops / (ms_k * 1e-3) / 1e12
+    which = "H" if ms_h >= ms_w else "W"
+    pmc = pmc_static(M, Nloc, K)
+    alg_bytes = algorithmic_bytes(M, Nloc, K)[0 if which == "H" else 1]
+    traffic = pmc["hbm_bytes_per_launch"][which] if pmc else None
     if shard is not None:
         # torch.distributed path: event pairs on the shard's stream around the all-reduce and around the whole iteration
         ev = []
@@ -302,8 +317,10 @@ def main():
             "config": {"workload": f"update_div KL-NMF, M={M} N={Ntot} R={K} fp32"
                                    + (f" ({Nloc} columns per GPU, H/X column-sharded, W replicated, all-reduce via {comm_used})" if sharded
                                       else {"cfg3": " (BASELINE config 3)", "cfg2": " (BASELINE config 2)", "gold": " (the reference's own problem)", "paper": " (the paper's example)",
+                                            "gold100": " (the reference's own problem at R = 100)", "gold200": " (the reference's own problem at R = 200)",
                                             "cfg4": " (BASELINE config 4, whole on one GPU)", "cfg5": " (BASELINE config 5, whole on one GPU)"}[args.preset]
-                                      if (M, Nloc, K) in ((4096, 65536, 256), (1024, 4096, 64), (4096, 350, 128), (512, 3445, 30), (4096, 262144, 256), (8192, 131072, 512)) else ""),
+                                      if (M, Nloc, K) in ((4096, 65536, 256), (1024, 4096, 64), (4096, 350, 128), (4096, 350, 100), (4096, 350, 200), (512, 3445, 30),
+                                                          (4096, 262144, 256), (8192, 131072, 512)) else ""),
                        "M": M, "N": Ntot, "R": K, "path": "fused" if s.path == ng.PATH_FUSED else "unfused",
                        "hipgraph": (not args.no_graph) and shard is None,
                        "parallelism": f"N-sharded x{world}" if sharded else "single GPU"},
@@ -311,9 +328,19 @@ def main():
             "kl_before": kl0, "kl_after": kl1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None,     # HBM bytes are a PMC quantity: not collected by this run, see pmc_static
-                         "pmc_static": PMC_STATIC.get((M, Nloc, K)),
-                         "kernel": "%s (%s-step launch, the slower of the two)" % (s.describe(), "H" if ms_h >= ms_w else "W"),
+                         # the fraction of peak of the WHOLE iteration (8*M*N*K flop over ms_per_step: helper launches, launch gaps and
+                         # the shorter half-step included) -- the figure to quote for a shape; `frac` is the dominant launch alone
+                         "frac_whole_iteration": tflops / (PEAK_FP32_MFMA_TFLOPS * world),
+                         # HBM bytes per launch of the dominant kernel: PMC counters of the committed passes of this command
+                         # (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), not collected by this run; null where no pass is committed
+                         "traffic": traffic,
+                         "traffic_source": pmc["source"] if pmc else None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "hbm_tbps": (traffic / (ms_k * 1e-3) / 1e12) if traffic else None,
+                         "algorithmic_tbps": alg_bytes / (ms_k * 1e-3) / 1e12,
+                         "mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"][which] if pmc else None,
+                         "kernel": "%s (%s-step launch, the slower of the two)" % (s.describe(), which),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,
                          "eager_event_ms_h_step": eager_h, "eager_event_ms_w_step": eager_w,

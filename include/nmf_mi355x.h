@@ -118,13 +118,15 @@ typedef struct {
                              * the chip, K <= 256); -1 = never (the 64-column kernel of the large configurations) */
     int   n_devices;        /* update_div / update_div_ex with host matrices: how many GPUs of this node share the work (columns of
                              * X and H are sharded, W is replicated, one RCCL all-reduce of [Z*H' ; rowsum(H)] per iteration inside
-                             * each device's hipGraph; one host thread per device, all inside the call).  0 = automatic: every visible
-                             * device when the problem is large enough to amortise the all-reduce (nmf_worth_sharding; the
-                             * environment variable NMF_DEVICES=<n>|all overrides) and `device` does not pin one, else one; 1 = one;
-                             * n > 1 = exactly n.  Every wait of a sharded run has a deadline (NMF_COMM_TIMEOUT_S, default 30 s for the
-                             * first collective): a rank that never arrives gets the group aborted and the call NMF_ERR_COMM; under the
-                             * automatic choice the call then runs on one GPU instead (W.mat / H.mat are written only by a run that
-                             * succeeded on every rank).  update_div_restarts: the number of workers the restarts are dealt to */
+                             * each device's hipGraph; one host thread per device, all inside the call).  SEVERAL GPUS ARE OPT-IN: the
+                             * N > 1 path is tested with emulated ranks and one-rank RCCL communicators only -- no multi-GPU node has run
+                             * it yet -- so 0 (default) = ONE GPU unless the environment asks (NMF_DEVICES=<n>|all forces a count,
+                             * NMF_DEVICES=auto takes every visible device when nmf_worth_sharding says the problem amortises the
+                             * all-reduce) and `device` does not pin one; 1 = one; n > 1 = exactly n.  Every wait of a sharded run has a
+                             * deadline (NMF_COMM_TIMEOUT_S, default 30 s for the first collective): a rank that never arrives gets the
+                             * group aborted and the call NMF_ERR_COMM; when the request came from the environment the call then runs on
+                             * one GPU instead (W.mat / H.mat are written only by a run that succeeded on every rank).
+                             * update_div_restarts: the number of workers the restarts are dealt to */
     const int *devices;     /* optional list of n_devices HIP ordinals; NULL = device, device + 1, ... (device < 0: from 0).  With
                              * n_devices = 1 an explicit list still takes the multi-device driver (one thread, one RCCL rank) */
     int   emulate_shards;   /* G > 1: run the multi-device driver with G ranks on ONE device, the all-reduce replaced by a
@@ -262,9 +264,10 @@ void *nmf_solver_stream(nmf_solver *s);
  * each pair's final KL.
  * Several GPUs ("replicas only", below the size where sharding ONE problem pays): restart i runs on worker i % G, one host
  * thread + one batched solver + one copy of X per worker, no communicator and no collective.  opts->n_devices = G > 1
- * (optionally with opts->devices, which may name a device more than once) forces G workers; 0 = automatic: every visible
- * device when the call holds at least ~0.5 s of single-GPU work (5e13 flop; bringing up a device costs a few hundred
- * milliseconds), unless opts->device pins one (NMF_DEVICES=<n>|all overrides either way); 1 = one device.  Needs X.mat (host).  Every restart
+ * (optionally with opts->devices, which may name a device more than once) forces G workers; 0 = one device unless the
+ * environment asks (NMF_DEVICES=<n>|all; NMF_DEVICES=auto: every visible device when the call holds at least ~0.5 s of
+ * single-GPU work, 5e13 flop -- bringing up a device costs a few hundred milliseconds) and opts->device does not pin one;
+ * 1 = one device.  Needs X.mat (host).  Every restart
  * gets the same kernels and split counts wherever it runs: its result is bit-identical to the one-device call's.
  * ------------------------------------------------------------------------------------- */
 int  update_div_restarts(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts *opts,
@@ -284,7 +287,7 @@ void nmf_comm_destroy(nmf_comm *c);
  * (a different major version is refused at load) */
 int  nmf_comm_library_info(char *buf, int buflen);
 
-/* 1 if sharding an M x N x K problem over n_devices GPUs amortises the per-iteration all-reduce (what n_devices = 0 uses) */
+/* 1 if sharding an M x N x K problem over n_devices GPUs amortises the per-iteration all-reduce (what NMF_DEVICES=auto uses) */
 int  nmf_worth_sharding(int M, int N, int K, int n_devices);
 
 /* diagnostics: with recording on, every launcher of a fused half-step / check kernel notes the demangled name of the

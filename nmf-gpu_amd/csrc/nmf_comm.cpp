@@ -39,17 +39,28 @@ struct Api {
 Api g_api;
 std::mutex g_api_mu;
 
-// The function table is typed by <rccl/rccl.h> (NCCL_VERSION_CODE of the ROCm this library was compiled against) while the
-// shared object comes from wherever the process finds "librccl.so.1" -- under PyTorch that is torch's bundled build, not
-// /opt/rocm's.  The entry points used here (all-reduce, init, destroy, abort, 128-byte unique id) have kept their signatures
-// through NCCL 2.x; a different MAJOR version is refused, the loaded version and path are reported (nmf_comm_library_info).
+// The function table is typed by <rccl/rccl.h> (NCCL_VERSION_CODE of the ROCm this library was compiled against).  Which shared
+// object it binds to: one the process has ALREADY mapped if there is one (under PyTorch that is torch's bundled build; two RCCLs in
+// one process would each set up their own transports), else the ROCm installation's own -- the one the header belongs to -- and
+// only then whatever the loader finds under the bare name.  The entry points used here (all-reduce, init, destroy, abort, 128-byte
+// unique id) have kept their signatures through NCCL 2.x; a different MAJOR version is refused, an older minor than the header's
+// is reported once on stderr, the loaded version and path are available through nmf_comm_library_info.
 bool load_api() {
     std::lock_guard<std::mutex> lock(g_api_mu);
     if (g_api.ok) return true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        g_api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    for (const char *n : {"librccl.so.1", "librccl.so"}) {
+        g_api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);   // already in the process?
         if (g_api.handle) break;
+    }
+    if (!g_api.handle) {
+        char rocm[512];
+        const char *root = getenv("ROCM_PATH");
+        snprintf(rocm, sizeof rocm, "%s/lib/librccl.so.1", (root && root[0]) ? root : "/opt/rocm");
+        const char *names[] = {rocm, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+        for (const char *n : names) {
+            g_api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (g_api.handle) break;
+        }
     }
     if (!g_api.handle) { fprintf(stderr, "nmf_comm: cannot dlopen librccl: %s\n", dlerror()); return false; }
     g_api.GetUniqueId = (decltype(&ncclGetUniqueId))dlsym(g_api.handle, "ncclGetUniqueId");
@@ -69,6 +80,9 @@ bool load_api() {
                 g_api.path, g_api.version, NCCL_MAJOR, NCCL_VERSION_CODE);
         return false;
     }
+    if (g_api.version && g_api.version < NCCL_VERSION_CODE)
+        fprintf(stderr, "nmf_comm: note: %s is RCCL %d.%d.%d, older than the rccl.h this library was built against (%d.%d.%d); the entry points used "
+                        "are unchanged across 2.x\n", g_api.path, g_api.version / 10000, (g_api.version / 100) % 100, g_api.version % 100, NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
     g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce;
     return g_api.ok;
 }
@@ -127,7 +141,14 @@ struct RcclGroup {
 };
 
 struct nmf_comm {
-    ncclComm_t comm = nullptr;
+    // The RCCL handle.  ncclCommAbort frees it, and the thread that aborts a group is usually not the thread that uses this
+    // communicator: a user takes call_mu, re-checks `aborted`, loads the handle and keeps call_mu until its RCCL call has
+    // returned; the aborter marks every member aborted first, takes the handle out (exchange with nullptr) and then waits for
+    // call_mu -- briefly: a rank between its check and the end of an ordinary enqueue finishes first, so the handle is never
+    // freed under it; a rank that stays BLOCKED inside the call (RCCL waiting for a dead peer) is exactly what ncclCommAbort
+    // exists to wake, and gets it after the grace period.
+    std::atomic<ncclComm_t> comm{nullptr};
+    std::timed_mutex call_mu;
     int rank = 0, nranks = 1;
     std::shared_ptr<EmuGroup> emu;   // set: a same-device emulated group instead of an RCCL communicator
     std::shared_ptr<RcclGroup> grp;  // set: one of the communicators of an ncclCommInitAll group
@@ -175,7 +196,9 @@ extern "C" int nmf_comm_init_rank(nmf_comm **out, const unsigned char id[NMF_COM
     memcpy(&u, id, sizeof u);
     nmf_comm *c = new nmf_comm();
     c->rank = rank; c->nranks = nranks;
-    const ncclResult_t rc = g_api.CommInitRank(&c->comm, nranks, u, rank);
+    ncclComm_t h = nullptr;
+    const ncclResult_t rc = g_api.CommInitRank(&h, nranks, u, rank);
+    c->comm = h;
     if (rc != ncclSuccess) {
         fprintf(stderr, "nmf_comm: ncclCommInitRank failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
         delete c;
@@ -190,9 +213,12 @@ extern "C" void nmf_comm_destroy(nmf_comm *c) {
     if (c->grp) {
         std::lock_guard<std::mutex> lk(c->grp->mu);
         for (auto &m : c->grp->members) if (m == c) m = nullptr;
-        if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);   // nullptr after an abort
-        c->comm = nullptr;
-    } else if (c->comm && g_api.ok) g_api.CommDestroy(c->comm);
+        const ncclComm_t h = c->comm.exchange(nullptr);   // nullptr after an abort
+        if (h && g_api.ok) g_api.CommDestroy(h);
+    } else {
+        const ncclComm_t h = c->comm.exchange(nullptr);
+        if (h && g_api.ok) g_api.CommDestroy(h);
+    }
     delete c;
 }
 
@@ -248,14 +274,23 @@ void nmf_comm_abort(nmf_comm *c) {
     c->aborted = true;
     if (c->emu) { c->emu->abort(); return; }
     if (!g_api.ok || !g_api.CommAbort) return;
+    // no new RCCL call starts on `m` once m->aborted is set (allreduce_impl checks it under call_mu); one that is under way gets a
+    // grace period to return before its handle is freed (see nmf_comm::comm)
+    auto abort_one = [](nmf_comm *m) {
+        const ncclComm_t h = m->comm.exchange(nullptr);
+        if (!h) return;
+        std::unique_lock<std::timed_mutex> quiet(m->call_mu, std::defer_lock);
+        (void)quiet.try_lock_for(std::chrono::milliseconds(200));
+        (void)g_api.CommAbort(h);
+    };
     if (c->grp) {   // every communicator of the group: the peers' kernels poll their OWN communicator's abort flag
         std::lock_guard<std::mutex> lk(c->grp->mu);
         c->grp->aborted = true;
-        for (nmf_comm *m : c->grp->members)
-            if (m && m->comm) { (void)g_api.CommAbort(m->comm); m->comm = nullptr; m->aborted = true; }
+        for (nmf_comm *m : c->grp->members) if (m) m->aborted = true;
+        for (nmf_comm *m : c->grp->members) if (m) abort_one(m);
         return;
     }
-    if (c->comm) { (void)g_api.CommAbort(c->comm); c->comm = nullptr; }
+    abort_one(c);
 }
 long nmf_comm_heartbeat(const nmf_comm *c) { return c ? c->beat.load(std::memory_order_relaxed) : 0; }
 bool nmf_comm_aborted(const nmf_comm *c) {
@@ -332,8 +367,12 @@ static int allreduce_impl(nmf_comm *c, void *buf, size_t count, ncclDataType_t d
     }
     if (c && nmf_comm_aborted(c)) return NMF_ERR_COMM;
     if (c && c->emu) return dtype == ncclFloat32 ? emu_allreduce(c, (float *)buf, count, stream) : emu_allreduce(c, (double *)buf, count, stream);
-    if (!c || !c->comm) return NMF_ERR_ARG;
-    const ncclResult_t rc = g_api.AllReduce(buf, buf, count, dtype, ncclSum, c->comm, stream);
+    if (!c) return NMF_ERR_ARG;
+    std::lock_guard<std::timed_mutex> in_call(c->call_mu);   // nmf_comm_abort frees the handle only after this call has returned (or stayed blocked)
+    if (nmf_comm_aborted(c)) return NMF_ERR_COMM;
+    const ncclComm_t h = c->comm.load();
+    if (!h) return NMF_ERR_COMM;
+    const ncclResult_t rc = g_api.AllReduce(buf, buf, count, dtype, ncclSum, h, stream);
     if (rc != ncclSuccess) {
         fprintf(stderr, "nmf_comm: ncclAllReduce failed: %s\n", g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
         return NMF_ERR_COMM;

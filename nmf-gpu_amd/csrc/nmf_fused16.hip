@@ -1,428 +1,59 @@
-// nmf_fused16.hip -- the production fused half-step of update_div (cuda/nmf.cu:118-176) for 64 <= K <= 512:
-// 16 owned columns per wave on v_mfma_f32_16x16x4_f32, and the KL check built from the same code.
-#include "nmf_device.h"
+// nmf_fused16.hip -- dispatch of the 16-column fused half-step (nmf_fused16_impl.h) over its K = 16 KT instantiations
+// (nmf_fused16_inst.hip): half-steps, the KL check and C = W * H.
+#include "nmf_fused16_impl.h"
 
 namespace nmf {
 
-// =====================================================================================
-// Fused half-step for 256 < K <= 512 (BASELINE config 5 has R = 512): same algorithm as v3 on
-// v_mfma_f32_16x16x4_f32 with 16 owned columns per wave, so that the K x 16 accumulator (16*NB
-// registers) and the K B-operands of product 1 (16*NB registers) fit the register file, NB = K/64.
-// Lane maps of the 16x16x4 form (lane l: j = l & 15, kq = l >> 4):
-//     A operand = A[row j][k kq],  B operand = B[k kq][col j],  result reg r = D[4 kq + r][j]
-// so register r of a finished 16x16 tile is the B operand of a step whose four k indices are the tile
-// rows 4 kq + r: the quotient again feeds product 2 straight from the accumulator registers.
-// Product 1 runs two interleaved chains (the two 16-row halves of the 32-row chunk): the 16x16x4 MFMA
-// issues every 32 cycles but needs 40 between dependent ones.
-// k index of product-1 step s in lane group kq: 64 (s >> 4) + 16 kq + (s & 15): per-lane contiguous runs
-// of 16 (16-B loads of the owned factor) and, with 33-float LDS rows, 32 distinct banks per half-wave.
-// CHECK = true turns the kernel into the KL / rel-L1 check (product 1 only), see check_kernel.
-// GEMM = true (H-step orientation only) keeps product 1 alone and stores it: C = W * H for K <= 512, the reference's
-// matrix_multiply (cuda/matrix.cu:97-105) on the W*H shape at the rate of the fused loop (a.U_out = C, ld = Mp; a.X unused).
-// =====================================================================================
-typedef const __attribute__((address_space(1))) char *global_bytes;
-#define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-constexpr int kXt16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
+#define NMF_K16_EXTERN(KT)                                                                                                   \
+    extern template hipError_t launch_fused_k16<KT>(const FusedArgs &, bool, hipStream_t);                                   \
+    extern template hipError_t launch_check_k16<KT>(const float *, const float *, const float *, int, int, int, double *, hipStream_t, int, size_t, size_t); \
+    extern template hipError_t launch_gemm_k16<KT>(const float *, const float *, float *, int, int, int, hipStream_t);
+NMF_K16_ALL(NMF_K16_EXTERN)
+#undef NMF_K16_EXTERN
 
-template <int NB, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1, bool GEMM = false>
-__global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, double *__restrict__ chk_part) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = 64 * NB;
-    constexpr int VBUF = K * kLdv;
-    constexpr int N1 = 16 * NB;      // product-1 steps per 16-row tile
-    constexpr int NT = 4 * NB;       // 16 x 16 accumulator tiles
-    constexpr int NST = 2 * NB;      // staged 16-B pieces per thread per chunk
-    constexpr int D = kRing;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
-    const int P = WSTEP ? a.Np : a.Mp;
-    const int Q = WSTEP ? a.Mp : a.Np;
-    const int nsplit = a.nsplit;
-    const bool x_in_range = a.x_in_range != 0;
-    const int split = blockIdx.x % nsplit;
-    const int qblk = blockIdx.x / nsplit;
-    int q0 = (qblk * 4 + wave) * 16;
-    const bool active = q0 < Q;
-    if (!active) q0 = Q - 16;
-    const size_t pair = CHECK ? (size_t)blockIdx.y : 0;   // the check of a batched solver: one launch over all its pairs (FusedArgs::strideW)
-    const float *__restrict__ V = (WSTEP ? a.H : a.W) + pair * (WSTEP ? a.strideH : a.strideW);
-    const float *__restrict__ U = (WSTEP ? a.W : a.H) + pair * (WSTEP ? a.strideW : a.strideH);
-    const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
-    const int nchunks = P / 32;
-    const int cps = (nchunks + nsplit - 1) / nsplit;
-    const int c_begin = split * cps;
-    const int c_end = (c_begin + cps < nchunks) ? (c_begin + cps) : nchunks;
-
-    // B operands of product 1: ub[s] = U(k(s, kq), q0 + j)
-    float ub[N1];
-    if (!WSTEP) {
-        const float *__restrict__ col = U + (size_t)(16 * kq) + (size_t)(q0 + j) * ldu;
-#pragma unroll
-        for (int sb = 0; sb < NB; ++sb)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
-                ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
-            }
-    } else {
-#pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(64 * (s >> 4) + 16 * kq + (s & 15)) * ldu];
-    }
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double kl = 0.0, dabs = 0.0, xabs = 0.0;
-    // FusedArgs::vsum_part: wave w of q-block b sums row 4 b + w of H over this split's columns
-    const bool vsum_on = WSTEP && PARTIAL && a.vsum_part != nullptr;
-    const int vrow_raw = qblk * 4 + wave, vrow = vrow_raw < K ? vrow_raw : K - 1;
-    float vs_acc = 0.f;
-
-    if (c_begin < c_end) {
-        const unsigned voff0 = 4u * (WSTEP ? (unsigned)(4 * (tid & 7)) + (unsigned)((tid >> 3) & 31) * (unsigned)ldv
-                                           : (unsigned)(4 * (tid & 7)) + (unsigned)(tid >> 3) * (unsigned)ldv);
-        const unsigned vstep = 4u * (WSTEP ? 32u : 32u * (unsigned)ldv);
-        const size_t vchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldv : (size_t)32);
-        // X tile (32 p x 16 q): H-step 16 columns of 128 B (8 lanes per column), W-step 32 rows of 64 B (4 lanes per row)
-        const unsigned xoff0 = WSTEP ? 4u * ((unsigned)(4 * (lane & 3)) + (unsigned)(lane >> 2) * (unsigned)ldx)
-                                     : 4u * ((unsigned)(4 * (lane & 7)) + (unsigned)(lane >> 3) * (unsigned)ldx);
-        const unsigned xstep = WSTEP ? 4u * 16u * (unsigned)ldx : 4u * 8u * (unsigned)ldx;
-        const char *__restrict__ xbase = reinterpret_cast<const char *>(WSTEP ? a.X + (size_t)q0 : a.X + (size_t)q0 * (size_t)ldx);
-        const size_t xchunk = 4 * (WSTEP ? (size_t)32 * (size_t)ldx : (size_t)32);
-        float *xt = smem + 2 * VBUF + wave * kXt16Floats;   // no __restrict__: written and read back within the wave
-        float *xt_w = WSTEP ? xt + (lane >> 2) * 20 + 4 * (lane & 3) : xt + (lane >> 3) * kXtLd + 4 * (lane & 7);
-        const float *xt_r = WSTEP ? xt + 4 * kq * 20 + j : xt + j * kXtLd + 4 * kq;
-        const int p1_off = 16 * kq * kLdv + j;     // + (64 (s>>4) + (s&15)) * kLdv + 16 T
-        const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
-
-        f32x4 st[NST];
-        f32x4 xg[2];
-        float xr[8];
-        unsigned vo = voff0, xo = xoff0;
-        const char *__restrict__ vcur = reinterpret_cast<const char *>(V);
-        const char *__restrict__ xcur = xbase;
-        auto set_chunk = [&](int ch) {
-            vo = voff0; xo = xoff0;
-            asm volatile("" : "+v"(vo), "+v"(xo));
-            vcur = reinterpret_cast<const char *>(V) + (size_t)ch * vchunk;
-            xcur = xbase + (size_t)ch * xchunk;
-        };
-        // the uniform part of every address is pinned in an SGPR pair (scalar adds are free next to the MFMAs;
-        // left alone the compiler chains 64-bit VALU adds through the per-lane address instead)
-        auto stage_load_one = [&](int q) {
-            global_bytes base = (global_bytes)(vcur + (size_t)q * (size_t)vstep);
-            asm volatile("" : "+s"(base));
-            st[q] = *(const __attribute__((address_space(1))) f32x4 *)(base + vo);
-        };
-        auto x_load_one = [&](int i) {
-            global_bytes base = (global_bytes)(xcur + (size_t)i * (size_t)xstep);
-            asm volatile("" : "+s"(base));
-            xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
-        };
-        auto stage_store_one = [&](float *__restrict__ vl, int w) {
-            const int q = w / 4, cc = w % 4;
-            if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
-            else        { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
-        };
-        auto x_relayout = [&]() {
-            if (!WSTEP) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(xt_w + 8 * i * kXtLd) = xg[i];
-#pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xt_r + 16 * T);
-                    xr[4 * T] = v[0]; xr[4 * T + 1] = v[1]; xr[4 * T + 2] = v[2]; xr[4 * T + 3] = v[3];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(xt_w + 16 * i * 20) = xg[i];
-#pragma unroll
-                for (int T = 0; T < 2; ++T)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xr[4 * T + r] = xt_r[(16 * T + r) * 20];
-            }
-        };
-
-        set_chunk(c_begin);
-#pragma unroll
-        for (int q = 0; q < NST; ++q) stage_load_one(q);
-        if (!GEMM) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) x_load_one(i);
-        }
-#pragma unroll
-        for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, w);
-        if (!GEMM) x_relayout();
-        __syncthreads();
-        for (int ch = c_begin; ch < c_end; ++ch) {
-            const int par = (ch - c_begin) & 1;
-            const float *__restrict__ vb = smem + par * VBUF;
-            float *__restrict__ vn = smem + (par ^ 1) * VBUF;
-            const int chn = (ch + 1 < c_end) ? ch + 1 : ch;
-            set_chunk(chn);
-            // ---- product 1: two interleaved chains, step index e = 2 s + T
-            const lds_float *b1 = (const lds_float *)vb + p1_off;
-            // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
-            float vs_in = 0.f;
-            if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
-            constexpr int E1 = 2 * N1;
-            float ar[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) ar[e] = lds_ld(b1 + (64 * ((e >> 1) >> 4) + ((e >> 1) & 15)) * kLdv + 16 * (e & 1));
-            if (OCC > 1) __builtin_amdgcn_s_setprio(1);
-            f32x4 s0, s1;
-            constexpr int NLOAD = NST + 2;
-            constexpr int G = E1 / (NLOAD + 1);
-#pragma unroll
-            for (int e = 0; e < E1; ++e) {
-                const int s = e >> 1;
-                if (NB >= 7) {
-                    // K >= 448 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
-                    // in front of it and its hazard recogniser cannot see into the asm (nmf_split16.hip, K = 256, came out ~1 % wrong
-                    // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
-                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
-                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
-                }
-                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
-                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
-                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
-                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
-                if (e + D < E1) {
-                    const int en = e + D;
-                    ar[e % D] = lds_ld(b1 + (64 * ((en >> 1) >> 4) + ((en >> 1) & 15)) * kLdv + 16 * (en & 1));
-                }
-                if (GEMM || CHECK) {
-                    // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
-                    // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: exactly 4*NST)
-                    constexpr int NLD = GEMM ? NST : NST + 2;   // the check also fetches the next X tile (first: it is used first)
-                    constexpr int GL = (E1 / 2) / (NLD + 1);
-                    if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {
-                        const int l = e / GL - 1;
-                        if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (e >= E1 / 2 && (e - E1 / 2) % 2 == 0 && (e - E1 / 2) / 2 < 4 * NST) {
-                        stage_store_one(vn, (e - E1 / 2) / 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
-                    const int l = e / G - 1;
-                    if (l < 2) x_load_one(l); else stage_load_one(l - 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
-            if (OCC > 1) __builtin_amdgcn_s_setprio(0);
-            if (GEMM) {   // lane holds S(p0 + 16 T + 4 kq + r, q0 + j): two 16-B stores per chunk, 64 B contiguous per column and half
-                if (active) {
-                    float *c = a.U_out + (size_t)(q0 + j) * (size_t)a.Mp + (size_t)ch * 32 + 4 * kq;
-                    *reinterpret_cast<f32x4 *>(c) = s0;
-                    *reinterpret_cast<f32x4 *>(c + 16) = s1;
-                }
-                __syncthreads();
-                continue;
-            }
-            if (CHECK) {
-                float fkl = 0.f, fd = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float x = xr[r], y = clamp_eps(r < 4 ? s0[r] : s1[r - 4]);
-                    fkl = __builtin_fmaf(x, log2_hw(y), fkl); fd += fabsf(x - y);   // the X-only terms of cuda/matrix.cu:592,517-518 are summed once at upload
-                }
-                kl += (double)fkl; dabs += (double)fd;
-                x_relayout();
-                __syncthreads();
-                continue;
-            }
-            // ---- first operands of product 2, then the quotient in one VALU block
-            const lds_float *b2 = (const lds_float *)vb + p2_off;
-            constexpr int E2 = 8 * NT;   // order: (T, r) outer, tile t inner
-            float a2[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
-            float z[8];
-            __builtin_amdgcn_sched_barrier(0);
-            quotient8<DIV>(xr, s0, s1, z, x_in_range);
-            if (WSTEP && PARTIAL) vs_acc += vs_in;
-            __builtin_amdgcn_sched_barrier(0);
-            x_relayout();
-            if (OCC > 1) __builtin_amdgcn_s_setprio(1);
-            // ---- product 2: NT independent accumulators
-            constexpr int E0 = E2 / 8;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {        // g = 4 T + r
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int e = g * NT + t;
-                    acc[t] = NMF_MFMA16(a2[e % D], z[g], acc[t]);
-                    if (e + D < E2) {
-                        const int en = e + D, gn = en / NT, tn = en % NT;
-                        a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
-                    }
-                    if (e >= E0 && (e - E0) % 2 == 0 && (e - E0) / 2 < 4 * NST) {
-                        stage_store_one(vn, (e - E0) / 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            if (OCC > 1) __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-        }
-    }
-    if (GEMM) return;
-    if (WSTEP && PARTIAL) {
-        if (vsum_on) {
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) vs_acc += __shfl_down(vs_acc, off, 32);
-            if (lane == 0 && vrow_raw < K) a.vsum_part[(size_t)split * K + vrow_raw] = vs_acc;
-        }
-    }
-    if (CHECK) {
-        if (!active) { kl = 0.0; dabs = 0.0; xabs = 0.0; }
-        block_reduce3(kl, dabs, xabs, chk_part + 3 * ((size_t)blockIdx.x + pair * gridDim.x), tid);
-        return;
-    }
-    if (!active) return;
-    // epilogue: lane holds Acc(k = 16 t + 4 kq + r, q0 + j)
-    if (PARTIAL) {
-        const size_t slab = WSTEP ? (size_t)a.Mp * a.Kp : (size_t)a.Kp * a.Np;
-        float *__restrict__ out = a.partials + (size_t)split * slab;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (!WSTEP) *reinterpret_cast<f32x4 *>(out + (size_t)(16 * t + 4 * kq) + (size_t)(q0 + j) * ldu) = acc[t];
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[(size_t)(q0 + j) + (size_t)(16 * t + 4 * kq + r) * ldu] = acc[t][r];
-            }
-        }
-    } else {
-        float *__restrict__ Uo = a.U_out;
-        const float *__restrict__ nrm = a.norm;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int k = 16 * t + 4 * kq;
-            if (!WSTEP) {
-                float *p = Uo + (size_t)k + (size_t)(q0 + j) * ldu;
-                f32x4 u = *reinterpret_cast<const f32x4 *>(p);
-                const f32x4 n4 = *reinterpret_cast<const f32x4 *>(nrm + k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) u[e] = u[e] * (acc[t][e] / n4[e]);
-                *reinterpret_cast<f32x4 *>(p) = u;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float *p = Uo + (size_t)(q0 + j) + (size_t)(k + r) * ldu;
-                    *p = *p * (acc[t][r] / nrm[k + r]);
-                }
-            }
-        }
-    }
+// the K the 16-column kernel computes on for a logical K: the next instantiated multiple of 16 (of 32 above 256), 0 = none
+int fused16_compute_k(int K) {
+    if (K <= 32 || K > 512) return 0;
+    const int kc = K <= 256 ? ((K + 15) & ~15) : ((K + 31) & ~31);
+    return kc < 48 ? 48 : kc;
 }
+static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 48 && Kc <= 512 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
 
-template <int NB, int OCC>
-static hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) {
-    const int Q = wstep ? a.Mp : a.Np;
-    const dim3 grid((unsigned)(((Q + 63) / 64) * a.nsplit)), block(256);
-    const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
-    const bool partial = a.partial != 0;
-    const bool fast = fused_fast_divide() || a.fast_divide;
-#define NMF_LAUNCH_K16(...)                                                                               \
-    do {                                                                                                  \
-        hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
-        if (e != hipSuccess) return e;                                                                    \
-        note_kernel((const void *)__VA_ARGS__, stream); \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
-    } while (0)
-    if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 1, false, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 1, false, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 1, false, OCC>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 1, false, OCC>);
-    } else {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, false, 0, false, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, false, true, 0, false, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, false, 0, false, OCC>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<NB, true, true, 0, false, OCC>);
-    }
-#undef NMF_LAUNCH_K16
-    return hipGetLastError();
-}
-
-template <int NB, int OCC>
-static hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
-                                   int batch, size_t strideW, size_t strideH) {
-    FusedArgs a;
-    a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
-    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
-    a.strideW = strideW; a.strideH = strideH;
-    const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
-    hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, lds);
-    if (e != hipSuccess) return e;
-    note_kernel((const void *)fused_step_kernel_k16<NB, false, false, 0, true, OCC>, stream);
-    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, true, OCC>), dim3((Np + 63) / 64, (unsigned)batch), dim3(256), lds, stream, a, part);
-    return hipGetLastError();
-}
-
-template <int NB, int OCC>
-static hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream) {
-    FusedArgs a;
-    a.W = A; a.H = B; a.X = nullptr; a.U_out = C; a.partials = nullptr; a.norm = nullptr;
-    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
-    const size_t lds = (size_t)2 * 64 * NB * kLdv * sizeof(float) + 4 * kXt16Floats * sizeof(float);
-    hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>, lds);
-    if (e != hipSuccess) return e;
-    note_kernel((const void *)fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>, stream);
-
-    hipLaunchKernelGGL((fused_step_kernel_k16<NB, false, false, 0, false, OCC, true>), dim3((Np + 63) / 64), dim3(256), lds, stream, a, (double *)nullptr);
-    return hipGetLastError();
-}
-
-// C(Mp x Np) = A(Mp x Kp) * B(Kp x Np), all contiguous column-major; Mp % 32 == 0, Np % 16 == 0, Kp in {64, 128, 256, 320..512 step 64}
+// C(Mp x Np) = A(Mp x Kp) * B(Kp x Np), all contiguous column-major; Mp % 32 == 0, Np % 16 == 0, Kp a multiple of 32 in [64, 512]
+// (the kernel stages whole 32-column pieces of A: no padding inside a caller's matrix to read instead)
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream) {
-    if ((Mp & 31) || (Np & 15) || Np < 16 || (Kp % 64) || (size_t)Mp * (size_t)Kp >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    switch (Kp / 64) {
-        case 1: return launch_gemm_k16<1, 2>(A, B, C, Mp, Np, Kp, stream);
-        case 2: return launch_gemm_k16<2, 2>(A, B, C, Mp, Np, Kp, stream);
-        case 4: return launch_gemm_k16<4, 2>(A, B, C, Mp, Np, Kp, stream);
-        case 5: return launch_gemm_k16<5, 1>(A, B, C, Mp, Np, Kp, stream);
-        case 6: return launch_gemm_k16<6, 1>(A, B, C, Mp, Np, Kp, stream);
-        case 7: return launch_gemm_k16<7, 1>(A, B, C, Mp, Np, Kp, stream);
-        case 8: return launch_gemm_k16<8, 1>(A, B, C, Mp, Np, Kp, stream);
+    if ((Mp & 31) || (Np & 15) || Np < 16 || (Kp % 32) || !k16_shape_ok(Kp, Kp) || (size_t)Mp * (size_t)Kp >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    switch (Kp / 16) {
+#define NMF_K16_CASE(KT) case KT: return launch_gemm_k16<KT>(A, B, C, Mp, Np, Kp, stream);
+        NMF_K16_ALL(NMF_K16_CASE)
+#undef NMF_K16_CASE
         default: return hipErrorInvalidValue;
     }
 }
 bool gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc) {
-    const int nb = k / 64;
-    return (m % 32 == 0) && (n % 16 == 0) && n >= 16 && (k % 64 == 0) && (nb == 1 || nb == 2 || (nb >= 4 && nb <= 8)) && lda == m && ldb == k && ldc == m &&
+    return (m % 32 == 0) && (n % 16 == 0) && n >= 16 && (k % 32 == 0) && k16_shape_ok(k, k) && lda == m && ldb == k && ldc == m &&
            (size_t)m * (size_t)k < ((size_t)1 << 31);
 }
 
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream) {
-    if (a.Kp % 64) return hipErrorInvalidValue;
-    switch (a.Kp / 64) {
-        case 1: return launch_fused_k16<1, 2>(a, wstep, stream);
-        case 2: return launch_fused_k16<2, 2>(a, wstep, stream);
-        case 4: return launch_fused_k16<4, 2>(a, wstep, stream);
-        case 5: return launch_fused_k16<5, 1>(a, wstep, stream);
-        case 6: return launch_fused_k16<6, 1>(a, wstep, stream);
-        case 7: return launch_fused_k16<7, 1>(a, wstep, stream);
-        case 8: return launch_fused_k16<8, 1>(a, wstep, stream);
+    const int kc = a.Kc > 0 ? a.Kc : a.Kp;
+    if (!k16_shape_ok(a.Kp, kc)) return hipErrorInvalidValue;
+    switch (kc / 16) {
+#define NMF_K16_CASE(KT) case KT: return launch_fused_k16<KT>(a, wstep, stream);
+        NMF_K16_ALL(NMF_K16_CASE)
+#undef NMF_K16_CASE
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                           int batch, size_t strideW, size_t strideH) {
-    if (Kp % 64) return hipErrorInvalidValue;
-    switch (Kp / 64) {
-        case 1: return launch_check_k16<1, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 2: return launch_check_k16<2, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 4: return launch_check_k16<4, 2>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 5: return launch_check_k16<5, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 6: return launch_check_k16<6, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 7: return launch_check_k16<7, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
-        case 8: return launch_check_k16<8, 1>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+    const int kc = Kc > 0 ? Kc : Kp;
+    if (!k16_shape_ok(Kp, kc)) return hipErrorInvalidValue;
+    switch (kc / 16) {
+#define NMF_K16_CASE(KT) case KT: return launch_check_k16<KT>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+        NMF_K16_ALL(NMF_K16_CASE)
+#undef NMF_K16_CASE
         default: return hipErrorInvalidValue;
     }
 }

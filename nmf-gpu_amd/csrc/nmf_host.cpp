@@ -102,6 +102,7 @@ static double now_s() {
 struct nmf_solver {
     int M = 0, N = 0, K = 0;       // logical (local) dims
     int Mp = 0, Np = 0, Kp = 0;    // padded device dims
+    int Kc = 0;                    // the K the chosen kernel computes on: a multiple of 16, <= Kp (FusedArgs::Kc / SplitArgs::Kc); the rest of Kp is zero padding
     int path = NMF_PATH_FUSED;
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
@@ -260,7 +261,7 @@ static int create_batched(nmf_solver **out, int M, int N, int K, int batch, cons
 // Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
 // launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
 // kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
-static int split_pad_k(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : (K <= 128 ? 128 : (K <= 256 ? 256 : 0))); }
+static int split_pad_k(int K) { return K <= 256 ? pad32(K) : 0; }   // K in HBM: padded to 32 like the reference; the kernel computes on split_compute_k(K)
 static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int kp = split_pad_k(K);
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
@@ -269,7 +270,7 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     // measured crossover (tools/crossover.py, iteration time of both families over M x N from 2^22 to 2^26 elements): the split
     // kernel is 5-26 % ahead up to 2^23 elements at K = 128 and 2^23-2^24 at K = 64 (a tie at 2^24), 3-14 % behind beyond; at
     // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25; at 128 < K <= 256 (one LDS image) 5-58 % ahead up to 2^22
-    const int lg = kp == 32 ? 26 : (kp == 64 ? 24 : (kp == 128 ? 23 : 22));
+    const int lg = kp <= 32 ? 26 : (kp <= 64 ? 24 : (kp <= 128 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
@@ -321,9 +322,12 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
         if (!fused_pad_k(K)) { set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
-        s->Kp = s->split ? split_pad_k(K) : fused_pad_k(K);   // 32/64/128/256 or 320/384/448/512; split kernel: 64/128
+        // K in HBM is padded to 32 (cuda/matrix.cuh:7) and the 16-column kernels compute on the next multiple of 16 (of 32 above 256)
+        s->Kp = s->split ? split_pad_k(K) : fused_pad_k(K);
+        s->Kc = s->split ? split_compute_k(K) : fused_compute_k(K);
     } else {
         s->Kp = pad32(K);
+        s->Kc = s->Kp;
     }
     s->path = path;
     s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
@@ -333,12 +337,12 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         // (measured: 3 % on cfg2 alone, but 17 % slower than two independent four-wave workgroups per CU once a batch fills
         //  the chip -- the eight waves share one barrier and run in phase -- so it stays an experiment: NMF_SPLIT_NW=8)
         const char *nwe = getenv("NMF_SPLIT_NW");
-        const bool nw8 = s->Kp == 64 && nwe && nwe[0] == '8';
+        const bool nw8 = s->Kc == 64 && nwe && nwe[0] == '8';
         s->nw_h = (nw8 && s->Mp % 256 == 0) ? 8 : 4;
         s->nw_w = (nw8 && s->Np % 256 == 0) ? 8 : 4;
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call (pick_split)
         s->split_batch = sb;
-        const int wpc = (s->Kp <= 64 || (s->Kp == 128 && sb > 1)) ? 2 : 1;   // workgroups the LDS image lets share a CU (split_args: single_image)
+        const int wpc = (s->Kp <= 64 || (s->Kp <= 128 && sb > 1)) ? 2 : 1;   // workgroups the LDS image lets share a CU (split_args: single_image)
         s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb, wpc);
         s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb, wpc);
         const int nsc_h = s->Mp / (32 * s->nw_h), nsc_w = s->Np / (32 * s->nw_w);
@@ -469,9 +473,9 @@ extern "C" int nmf_solver_path(const nmf_solver *s) { return s ? s->path : 0; }
 extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
-    else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KB=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kp / 32, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
+    else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
     else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
-    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<NB=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 64, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     return NMF_OK;
 }
@@ -696,7 +700,7 @@ static FusedArgs fused_args(nmf_solver *s) {
     FusedArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.norm = nullptr;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide > 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide > 0;
     a.x_in_range = s->fast_divide < 0 ? 0 : s->x_in_range;
     return a;
 }
@@ -705,10 +709,11 @@ static SplitArgs split_args(nmf_solver *s) {
     SplitArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
     a.nw_h = s->nw_h; a.nw_w = s->nw_w;
-    // K = 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
-    a.single_image = (s->Kp == 128 && s->split_batch > 1 && !getenv("NMF_SPLIT_DOUBLE")) || (s->Kp == 128 && getenv("NMF_SPLIT_SINGLE") != nullptr);
+    // 64 < K <= 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
+    const bool mid_k = s->Kp > 64 && s->Kp <= 128;
+    a.single_image = (mid_k && s->split_batch > 1 && !getenv("NMF_SPLIT_DOUBLE")) || (mid_k && getenv("NMF_SPLIT_SINGLE") != nullptr);
     a.Mv = (s->M + 31) & ~31; a.Nv = (s->N + 31) & ~31;
     a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np;
     a.active = s->active_d;
@@ -1065,7 +1070,7 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
         if (s->path == NMF_PATH_FUSED) {
             const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
             NMFCHK(ensure_x_consts(s));
-            HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+            HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st));
             HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out, st));
         } else {
             const size_t mn = (size_t)s->Mp * s->Np;
@@ -1093,7 +1098,7 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     // 4096 x 350 x 128: six, ~130 us) and sixteen of them one after the other were 2.7 ms of a 60 ms call -- at every
     // convergence check of a run with a threshold.  The fp64 composition (three small launches) stays per pair.
     const size_t part_stride = 3 * (size_t)s->chk_groups;
-    HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st, s->batch, (size_t)s->Mp * s->Kp, (size_t)s->Kp * s->Np));
+    HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st, s->batch, (size_t)s->Mp * s->Kp, (size_t)s->Kp * s->Np));
     for (int b = 0; b < s->batch; ++b) {
         const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
         HIPCHK(launch_check_compose(s->chk_part + (size_t)b * part_stride, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
@@ -1226,7 +1231,7 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 break;
             case NMF_T_CHECK:
                 if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
-                HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->chk_part, st));
+                HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st));
                 break;
             default:
 #ifdef NMF_DIAGNOSTICS   // make DIAG=1; the shipped library answers NMF_ERR_ARG
@@ -1293,9 +1298,9 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
 // ------------------------------------------------------------------------------ update_div
 int nmf_update_div_multi(matrix W, matrix H, matrix X, const nmf_opts &o, const int *devices, int G, bool emulate, nmf_result *res);   // nmf_multi.cpp
 
-// How many ranks, on which devices: nmf_opts.n_devices / devices / emulate_shards, NMF_DEVICES, NMF_EMULATE_SHARDS,
-// nmf_worth_sharding.  `automatic` = the caller did not ask for several devices (n_devices = 0 and no emulate_shards): the
-// choice came from the environment or the heuristic, and update_div_ex may fall back to one GPU if the sharded run fails.
+// How many ranks, on which devices: nmf_opts.n_devices / devices / emulate_shards, NMF_DEVICES, NMF_EMULATE_SHARDS.
+// `automatic` = the caller's options did not ask for several devices (n_devices = 0 and no emulate_shards): the choice came from
+// the environment, and update_div_ex may fall back to one GPU if the sharded run fails.
 static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, const matrix &X, int M, int N, int K,
                         std::vector<int> &devices, bool &emulate, bool &automatic) {
     devices.clear(); emulate = false; automatic = false;
@@ -1326,12 +1331,16 @@ static int plan_devices(const nmf_opts &o, const matrix &W, const matrix &H, con
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     if (want == 0) {
+        // Several GPUs are OPT-IN: the sharded path has never run on N > 1 real devices (no 8-GPU node was available to any round
+        // of this build), and a drop-in call must not take an unproven path by itself.  n_devices = 0 therefore means ONE GPU
+        // unless the environment asks: NMF_DEVICES=<n>|all forces, NMF_DEVICES=auto lets nmf_worth_sharding decide.
         automatic = true;
-        // a caller that names ONE device (nmf --device 3, update_div_ex(device = 3)) gets that device, as before sharding existed
+        // a caller that names ONE device (nmf --device 3, update_div_ex(device = 3)) gets that device
         if (o.device >= 0 && !o.devices) return NMF_OK;
         const char *e = getenv("NMF_DEVICES");
-        if (e && e[0]) want = (strcmp(e, "all") == 0) ? ndev : atoi(e);
-        else want = (ndev > 1 && nmf_worth_sharding(M, N, K, ndev)) ? ndev : 1;
+        if (!(e && e[0])) return NMF_OK;
+        if (strcmp(e, "auto") == 0) want = (ndev > 1 && nmf_worth_sharding(M, N, K, ndev)) ? ndev : 1;
+        else want = (strcmp(e, "all") == 0) ? ndev : atoi(e);
         if (want > ndev) want = ndev;
         if (want > N) want = N;
         if (want <= 1) return NMF_OK;
@@ -1574,8 +1583,8 @@ static int restarts_one_device(const matrix *W, const matrix *H, int n_restarts,
 // Which devices share the restarts ("replicas only": SURVEY 8e / 8f4 -- below the size where sharding one problem pays, a node's
 // GPUs are used by giving each its own restarts; no communicator, no collective, nothing to wait for but the threads).
 // nmf_opts.n_devices = n > 1 (with an optional `devices` list, which may name a device more than once: each entry is a worker
-// with its own solver and stream) forces; 0 = automatic: every visible device unless the caller pinned one (device >= 0) or
-// NMF_DEVICES=<n>|all says otherwise; 1 = the one device.
+// with its own solver and stream) forces; 0 = one device unless NMF_DEVICES=<n>|all|auto asks for more (and the caller did not
+// pin one with device >= 0); 1 = the one device.
 static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x, double flop, std::vector<int> &devices) {
     devices.clear();
     if (o.comm || o.stream || !host_x || n_restarts < 2) return;
@@ -1583,13 +1592,14 @@ static void plan_restart_devices(const nmf_opts &o, int n_restarts, bool host_x,
     if (want == 1 || want < 0) return;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
-    if (want == 0) {
+    if (want == 0) {   // opt-in, as for update_div: one device unless NMF_DEVICES=<n>|all|auto asks for more
         if (o.device >= 0 && !o.devices) return;
         const char *e = getenv("NMF_DEVICES");
-        // by itself the library spreads only work worth it: bringing up a device this process has not used yet costs a few
-        // hundred milliseconds, so below ~0.5 s of single-GPU work (5e13 flop) the restarts stay on one device
-        if (!(e && e[0]) && flop < 5e13) return;
-        want = (e && e[0]) ? ((strcmp(e, "all") == 0) ? ndev : atoi(e)) : ndev;
+        if (!(e && e[0])) return;
+        // auto: the library spreads only work worth it -- bringing up a device this process has not used yet costs a few hundred
+        // milliseconds, so below ~0.5 s of single-GPU work (5e13 flop) the restarts stay on one device
+        if (strcmp(e, "auto") == 0) { if (flop < 5e13) return; want = ndev; }
+        else want = (strcmp(e, "all") == 0) ? ndev : atoi(e);
         if (want > ndev) want = ndev;
     }
     if (want > n_restarts) want = n_restarts;

@@ -32,6 +32,8 @@ struct FusedArgs {
     float *partials;          // nsplit  > 1: nsplit slabs of Kp*Np (H-step) or Mp*Kp (W-step) floats
     const float *norm;        // Kp clamped normalisers (colsum(W) for the H-step, rowsum(H) for the W-step); nsplit == 1 only
     int Mp, Np, Kp;
+    int Kc = 0;               // 16-column kernel: the K its MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (rows / columns Kc .. Kp - 1 of
+                              //    the factors are zero padding); 0 = Kp.  The other families compute on Kp.
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
     int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
@@ -45,7 +47,8 @@ struct FusedArgs {
                               //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
-// the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 64 <= Kp <= 512; nmf_fused32.hip: Kp <= 256)
+// the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 48 <= Kc <= 512, every multiple of 16 up to 256 and
+// of 32 above; nmf_fused32.hip: Kp = 32, and 64 / 128 / 256 under NMF_FUSED_VARIANT=3)
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
 // 512 < Kp <= 1024 (a multiple of 128): two waves share 16 owned columns and split K (nmf_pair16.hip)
@@ -54,8 +57,9 @@ hipError_t launch_check_pair(const float *W, const float *H, const float *X, int
 // C = A * B through product 1 of the 16-column kernel (the W*H shape: tall A, K <= 512), see nmf_fused16.hip
 bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
-hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
+int        fused16_compute_k(int K);   // the multiple of 16 (of 32 above 256) the 16-column kernel computes on for 32 < K <= 512, else 0
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
 #ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library
@@ -79,17 +83,19 @@ struct SplitArgs {
     float *partials;          // nsplit  > 1
     float *vpart;             // nsplit  > 1
     int Mp, Np, Kp;
+    int Kc = 0;               // the K the MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (split_compute_k); 0 = Kp
     int Mv, Nv;               // M, N rounded up to 32: column groups beyond them hold only zero padding and get no workgroup
     int nsplit;
     int nw_h, nw_w;           // waves per workgroup (4 or 8) of the H- and the W-step: reduction length % (32 nw) == 0; 8 needs Kp == 64
     int force_partial;        // 1: raw slab + sums even with nsplit == 1 (sharded runs: the all-reduce operand)
-    int single_image;         // Kp == 128 only: one LDS image instead of two (two workgroups per CU; same arithmetic).  Kp == 256 always runs so
+    int single_image;         // 64 < Kc <= 128 only: one LDS image instead of two (two workgroups per CU; same arithmetic).  Kc > 128 always runs so
     int batch;
     size_t strideW, strideH;  // floats between consecutive pairs
     const int *active;        // optional [batch] flags: 0 = leave this pair untouched (it has converged)
     int fast_divide, x_in_range;
 };
 bool       split_step_supports(int Kp);
+int        split_compute_k(int K);   // the multiple of 16 (>= 32) the split kernel computes on for K <= 256, else 0
 size_t     split_step_lds_bytes(int Kp, int nw, bool double_buffered);
 hipError_t launch_split_step(const SplitArgs &a, bool wstep, hipStream_t stream);
 // q_valid: rows of W (W-step) / columns of H (H-step) that got a workgroup (SplitArgs::Mv / Nv); the rest is zero padding
@@ -124,10 +130,11 @@ hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp
 int        check_num_groups(int Np, int Kp);
 bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
-int        fused_pad_k(int K);             // K padded to an instantiated kernel size, 0 if the fused path cannot take it
+int        fused_pad_k(int K);             // K as the fused path pads it in HBM (a multiple of 32; of 128 above 512), 0 if the fused path cannot take it
+int        fused_compute_k(int K);         // K as the chosen fused kernel computes on it (FusedArgs::Kc): <= fused_pad_k(K), a multiple of 16
 // batch > 1: `batch` (W, H) pairs, strideW / strideH floats apart, in one launch (grid.y); pair b's check_num_groups triples
 // at part + 3 * check_num_groups * b.  Kp <= 512 (the batched solvers' range); the wave-pair kernel takes one pair at a time.
-hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp,
+hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc,
                         double *part, hipStream_t stream, int batch = 1, size_t strideW = 0, size_t strideH = 0);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
 constexpr int kXConstGroups = 1024;     // partial triples of launch_x_consts

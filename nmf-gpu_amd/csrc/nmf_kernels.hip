@@ -49,7 +49,7 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
     return use_k16(a.Kp) ? launch_fused16(a, wstep, stream) : launch_fused32(a, wstep, stream);
 }
 
-hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
+hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                         int batch, size_t strideW, size_t strideH) {
     if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
     if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
@@ -60,19 +60,27 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
         }
         return hipSuccess;
     }
-    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, Kc, part, stream, batch, strideW, strideH) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
 }
 
 // one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows
 bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 4 >= (size_t)Kp; }
 int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
-int fused_pad_k(int K) {   // padded K the fused kernels are instantiated for; 0 = not supported
+// K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 512 -- the 16-column kernel has an
+// instantiation for every multiple of 16 up to 256 and of 32 up to 512 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
+// an A/B switch) only exists for 32 / 64 / 128 / 256.  0 = not supported.
+int fused_pad_k(int K) {
     const int k32 = pad32(K);
-    if (k32 <= 256) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
-    const int k64 = (K + 63) & ~63;
-    if (k64 <= 512) return k64;
+    if (k32 <= 32) return 32;
+    if (k32 <= 256 && fused_variant() != 0) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
+    if (k32 <= 512) return k32;
     const int k128 = (K + 127) & ~127;        // the pair kernel splits K in two halves of whole 64-blocks
     return k128 <= kMaxFusedK ? k128 : 0;
+}
+int fused_compute_k(int K) {
+    const int kp = fused_pad_k(K);
+    if (!kp || !use_k16(kp)) return kp;
+    return fused16_compute_k(K);
 }
 int check_num_groups(int Np, int Kp) { return (Np + fused_cols_per_group(Kp) - 1) / fused_cols_per_group(Kp); }
 

@@ -52,27 +52,50 @@ def recording(ng):
     ng.record_kernels(old)
 
 
+K16_KTS = tuple(range(3, 17)) + tuple(range(18, 33, 2))   # every multiple of 16 from K = 48 to 256, of 32 from 288 to 512
+
+
 def test_every_instantiation_of_the_64_column_kernel(ng, oracle, recording):
-    """fused_step_kernel_k16<NB, WSTEP, PARTIAL, DIV, CHECK, OCC>: NB = K/64 in {1, 2, 4, 5, 6, 7, 8} (OCC = 2 up to NB = 4),
-    both half-steps, in-place and partial-slab epilogues, both quotients, and the CHECK instantiation of every NB"""
+    """fused_step_kernel_k16<KT, WSTEP, PARTIAL, DIV, CHECK, OCC, GEMM>: KT = K/16 in 3..16 (OCC = 2) and 18, 20, .. 32 (OCC = 1),
+    both half-steps, in-place and partial-slab epilogues, both quotients, and the CHECK instantiation of every KT.  The odd KT
+    (K = 48, 80, ... 240: a remainder block in the k map, a zero-padded half piece in the LDS image) are the round-4 additions."""
     seen = set()
-    for K, ns, fd in itertools.product((64, 128, 256, 320, 384, 448, 512), (1, 2), (0, 1)):
-        _half_steps(ng, oracle, 160, 208, K, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    for kt, ns, fd in itertools.product(K16_KTS, (1, 2), (0, 1)):
+        _half_steps(ng, oracle, 160, 208, 16 * kt, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
     want = set()
-    for nb in (1, 2, 4, 5, 6, 7, 8):
-        occ = "2" if nb <= 4 else "1"
+    for kt in K16_KTS:
+        occ = "2" if kt <= 16 else "1"
         for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
-            want.add(("fused_step_kernel_k16", (str(nb), w, p, d, "false", occ, "false")))
-        want.add(("fused_step_kernel_k16", (str(nb), "false", "false", "0", "true", occ, "false")))
+            want.add(("fused_step_kernel_k16", (str(kt), w, p, d, "false", occ, "false")))
+        want.add(("fused_step_kernel_k16", (str(kt), "false", "false", "0", "true", occ, "false")))
     assert want <= seen, sorted(want - seen)
 
 
-def test_every_instantiation_of_the_split_kernel(ng, oracle, recording):
-    """split_step_kernel_k16<KB, NW, WSTEP, PARTIAL, DIV, OCC, DB>: K = 32, 64 (four and eight waves), 128 (two LDS images
-    at one workgroup per CU; one image at two per CU), 256 (one image); both half-steps, both epilogues, both quotients"""
+def test_a_logical_k_between_two_instantiations_runs_the_next_multiple_of_16(ng, oracle, recording):
+    """K = 100 computes on 112 (KT = 7) in factors padded to 128; K = 200 on 208; K = 33 on 48; K = 270 on 288 (multiples of 32
+    above 256): the reference pads to 32 and nothing coarser (cuda/matrix.cuh:7)."""
     seen = set()
-    combos = [(32, {}, ("1", "4", "2", "true")), (64, {}, ("2", "4", "2", "true")), (64, {"NMF_SPLIT_NW": "8"}, ("2", "8", "2", "true")),
-              (128, {}, ("4", "4", "1", "true")), (128, {"NMF_SPLIT_SINGLE": "1"}, ("4", "4", "2", "false")), (256, {}, ("8", "4", "1", "false"))]
+    for K, kt in ((100, 7), (200, 13), (33, 3), (270, 18), (97, 7), (250, 16)):
+        seen.clear()
+        _half_steps(ng, oracle, 160, 208, K, seen, split_kernel=-1)
+        assert {a[0] for n, a in seen if n == "fused_step_kernel_k16"} == {str(kt)}, (K, seen)
+        seen.clear()
+        if K <= 256:
+            _half_steps(ng, oracle, 512, 768, K, seen, split_kernel=1)
+            assert {a[0] for n, a in seen if n == "split_step_kernel_k16"} == {str(kt)}, (K, seen)
+
+
+def test_every_instantiation_of_the_split_kernel(ng, oracle, recording):
+    """split_step_kernel_k16<KT, NW, WSTEP, PARTIAL, DIV, OCC, DB>: K = 32, 48, 64 (two LDS images, two workgroups per CU; K = 64 also
+    with eight waves), 80 .. 128 (two images at one workgroup per CU; one image at two per CU), 144 .. 256 (one image); both
+    half-steps, both epilogues, both quotients"""
+    seen = set()
+    combos = [(32, {}, ("2", "4", "2", "true")), (48, {}, ("3", "4", "2", "true")), (64, {}, ("4", "4", "2", "true")), (64, {"NMF_SPLIT_NW": "8"}, ("4", "8", "2", "true"))]
+    for kt in (5, 6, 7, 8):
+        combos.append((16 * kt, {}, (str(kt), "4", "1", "true")))
+        combos.append((16 * kt, {"NMF_SPLIT_SINGLE": "1"}, (str(kt), "4", "2", "false")))
+    for kt in range(9, 17):
+        combos.append((16 * kt, {}, (str(kt), "4", "1", "false")))
     for (K, env, _), ns, fd in itertools.product(combos, (1, 2), (0, 1)):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
@@ -82,9 +105,9 @@ def test_every_instantiation_of_the_split_kernel(ng, oracle, recording):
             for k, v in old.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     want = set()
-    for (_, _, (kb, nw, occ, db)) in combos:
+    for (_, _, (kt, nw, occ, db)) in combos:
         for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
-            want.add(("split_step_kernel_k16", (kb, nw, w, p, d, occ, db)))
+            want.add(("split_step_kernel_k16", (kt, nw, w, p, d, occ, db)))
     assert want <= seen, sorted(want - seen)
 
 

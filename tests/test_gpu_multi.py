@@ -255,3 +255,40 @@ def test_restarts_main_example_runs_two_workers_through_the_c_abi(oracle, tmp_pa
     for i in range(R):
         assert oracle.relF(oracle.read_bin(str(tmp_path / f"Wout{i}.bin")), ref[i][0]) < 1e-4
         assert oracle.relF(oracle.read_bin(str(tmp_path / f"Hout{i}.bin")), ref[i][1]) < 1e-4
+
+
+def test_concurrent_ranks_each_with_an_rccl_communicator_capture_and_replay_their_graphs(ng, oracle):
+    """What a one-GPU box can rehearse of the N > 1 run that no hardware has executed yet (round-3 VERDICT next 2c): several host
+    threads at once, each inside the multi-device driver with its OWN one-rank RCCL communicator on device 0 -- ncclCommInitAll,
+    the eager warm-up all-reduce, thread-local capture of the 32 / 8 / 1-iteration hipGraphs WITH the in-graph all-reduce, replay,
+    all-reduced KL checks, pooled streams -- concurrently, on different problems (a split-kernel shape, a 64-column shape, a
+    non-power-of-two K).  Every thread's result must equal, bit for bit, the same call made alone afterwards, and match the
+    oracle.  What this cannot contain is RCCL between devices: N > 1 stays unmeasured and opt-in."""
+    import threading
+    shapes = [(1024, 8192, 64), (512, 2048, 100), (2048, 4096, 256), (768, 3000, 48)]
+    probs = [oracle.gen_problem(M, N, K, seed=31 + i) for i, (M, N, K) in enumerate(shapes)]
+    kw = dict(max_iter=80, n_devices=1, devices=[0], converge_thresh=1e-30, iter_check=40, use_graph=1)
+
+    def run(i, out):
+        X, W, H = probs[i]
+        Wm, Hm = ng.Matrix(W.copy()), ng.Matrix(H.copy())
+        r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), **kw)
+        out[i] = (Wm.mat.copy(), Hm.mat.copy(), r)
+
+    together, alone = {}, {}
+    th = [threading.Thread(target=run, args=(i, together)) for i in range(len(shapes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(together) == len(shapes)          # no thread died in the driver
+    for i in range(len(shapes)):
+        run(i, alone)
+    for i, (M, N, K) in enumerate(shapes):
+        Wt, Ht, rt = together[i]
+        Wa, Ha, ra = alone[i]
+        assert rt["n_shards"] == 1 and rt["iterations"] == 80 and len(rt["kl"]) == 3 and rt["w_replicas_identical"] == 1
+        assert np.array_equal(Wt, Wa) and np.array_equal(Ht, Ha) and rt["kl"] == ra["kl"], (M, N, K)
+        X, W, H = probs[i]
+        Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 80, 40)
+        assert oracle.relF(Wt, Wr) < 1e-5 and oracle.relF(Ht, Hr) < 1e-5 and np.allclose(rt["kl"], klr, rtol=2e-5), (M, N, K)

@@ -55,6 +55,21 @@ def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
         assert np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all()
 
 
+@pytest.mark.parametrize("K", [48, 96, 100, 160, 192, 200, 224])
+@pytest.mark.parametrize("M,N,split_kernel", [(512, 768, 1), (1024, 4096, -1)])
+def test_k_between_the_powers_of_two_200_iterations_vs_oracle(ng, oracle, M, N, K, split_kernel):
+    """The K values of round-3 VERDICT item 1 (padded to 128 / 256 until round 3; now computed on the next multiple of 16 in factors
+    padded to 32 like the reference's, cuda/matrix.cuh:7): 200 iterations on one small shape through the split kernel and one
+    larger shape through the 64-column kernel, hipGraph replay, against the oracle.  Bound 1e-5 (north_star gate 1e-4)."""
+    X, W, H = oracle.gen_problem(M, N, K, seed=K)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=200, split_kernel=split_kernel, use_graph=1)
+    assert r["iterations"] == 200
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
+    eW, eH = _relF(oracle, Wm.mat, Wr), _relF(oracle, Hm.mat, Hr)
+    assert eW < 1e-5 and eH < 1e-5 and np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all(), (eW, eH)
+
+
 def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
     for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), True), ((256, 256, 300), False),
                             ((4096, 2048, 256), False), ((4096, 1024, 256), True),
@@ -402,8 +417,8 @@ def test_prepare_captures_without_running_and_describe_names_the_kernel(ng, orac
     b = s.download()
     s.close()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    for (shape, word) in (((1024, 4096, 64), "split_step_kernel_k16<KB=2>"), ((512, 3445, 30), "split_step_kernel_k16<KB=1>"), ((256, 256, 200), "split_step_kernel_k16<KB=8>"),
-                          ((4096, 65536, 256), "fused_step_kernel_k16<NB=4>"), ((256, 256, 700), "fused_step_kernel_pair<NBH=6>"), ((128, 128, 1100), "unfused")):
+    for (shape, word) in (((1024, 4096, 64), "split_step_kernel_k16<KT=4>"), ((512, 3445, 30), "split_step_kernel_k16<KT=2>"), ((256, 256, 200), "split_step_kernel_k16<KT=13>"),
+                          ((4096, 65536, 256), "fused_step_kernel_k16<KT=16>"), ((256, 256, 700), "fused_step_kernel_pair<NBH=6>"), ((128, 128, 1100), "unfused")):
         s = ng.Solver(*shape)
         assert word in s.describe(), (shape, s.describe())
         s.close()

@@ -7,21 +7,34 @@ import pytest
 
 @pytest.mark.parametrize("shape,batch,want", [
     # BASELINE configs 2-5 and the cfg4 / cfg5 shards of an 8-GPU run
-    ((1024, 4096, 64), 1, "split_step_kernel_k16<KB=2> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,4) batch=1"),
-    ((4096, 65536, 256), 1, "fused_step_kernel_k16<NB=4> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),
-    ((4096, 262144, 256), 1, "fused_step_kernel_k16<NB=4> Mp=4096 Np=262144 Kp=256 nsplit(h,w)=(1,8)"),
-    ((4096, 32768, 256), 1, "fused_step_kernel_k16<NB=4> Mp=4096 Np=32768 Kp=256 nsplit(h,w)=(1,8)"),
-    ((8192, 131072, 512), 1, "fused_step_kernel_k16<NB=8> Mp=8192 Np=131072 Kp=512 nsplit(h,w)=(1,4)"),
-    ((8192, 16384, 512), 1, "fused_step_kernel_k16<NB=8> Mp=8192 Np=16384 Kp=512 nsplit(h,w)=(1,4)"),
+    ((1024, 4096, 64), 1, "split_step_kernel_k16<KT=4> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,4) batch=1"),
+    ((4096, 65536, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),
+    ((4096, 262144, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=262144 Kp=256 nsplit(h,w)=(1,8)"),
+    ((4096, 32768, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=32768 Kp=256 nsplit(h,w)=(1,8)"),
+    ((8192, 131072, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=131072 Kp=512 nsplit(h,w)=(1,4)"),
+    ((8192, 16384, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=16384 Kp=512 nsplit(h,w)=(1,4)"),
     # the reference's own problem (matrix_export.py:4-7) and the paper's example
-    ((4096, 350, 128), 1, "split_step_kernel_k16<KB=4> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
-    ((512, 3445, 30), 1, "split_step_kernel_k16<KB=1> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,7) batch=1"),
+    ((4096, 350, 128), 1, "split_step_kernel_k16<KT=8> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
+    ((512, 3445, 30), 1, "split_step_kernel_k16<KT=2> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,7) batch=1"),
     # batched restarts: the split shrinks with the batch (profiles/r03_restart_sweep.log)
-    ((4096, 350, 128), 16, "split_step_kernel_k16<KB=4> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
-    ((4096, 350, 128), 4, "split_step_kernel_k16<KB=4> Mp=4096 Np=384 Kp=128 splits(h,w)=(8,1) batch=4"),
-    ((1024, 4096, 64), 16, "split_step_kernel_k16<KB=2> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,1) batch=16"),
-    ((1024, 4096, 64), 4, "split_step_kernel_k16<KB=2> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,2) batch=4"),
-    ((512, 3445, 30), 16, "split_step_kernel_k16<KB=1> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,1) batch=16"),
+    ((4096, 350, 128), 16, "split_step_kernel_k16<KT=8> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
+    ((4096, 350, 128), 4, "split_step_kernel_k16<KT=8> Mp=4096 Np=384 Kp=128 splits(h,w)=(8,1) batch=4"),
+    ((1024, 4096, 64), 16, "split_step_kernel_k16<KT=4> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,1) batch=16"),
+    ((1024, 4096, 64), 4, "split_step_kernel_k16<KT=4> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,2) batch=4"),
+    ((512, 3445, 30), 16, "split_step_kernel_k16<KT=2> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,1) batch=16"),
+    # K between the powers of two: padded to 32 in HBM like the reference (cuda/matrix.cuh:7), computed on the next multiple of 16
+    # (of 32 above 256) -- round 3 padded all of these to 128 / 256
+    ((4096, 65536, 96), 1, "fused_step_kernel_k16<KT=6> Mp=4096 Np=65536 Kp=96 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 100), 1, "fused_step_kernel_k16<KT=7> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 160), 1, "fused_step_kernel_k16<KT=10> Mp=4096 Np=65536 Kp=160 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 192), 1, "fused_step_kernel_k16<KT=12> Mp=4096 Np=65536 Kp=192 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 200), 1, "fused_step_kernel_k16<KT=13> Mp=4096 Np=65536 Kp=224 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 48), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=20> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),
+    ((4096, 350, 100), 1, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
+    ((4096, 350, 200), 1, "split_step_kernel_k16<KT=13> Mp=4096 Np=384 Kp=224 splits(h,w)=(11,1) batch=1"),
+    ((4096, 350, 100), 16, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
+    ((1024, 4096, 48), 1, "split_step_kernel_k16<KT=3> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,4) batch=1"),
     # the K ranges of the other families
     ((4096, 65536, 1024), 1, "fused_step_kernel_pair<NBH=8> Mp=4096 Np=65536 Kp=1024 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 600), 1, "fused_step_kernel_pair<NBH=5> Mp=4096 Np=65536 Kp=640 nsplit(h,w)=(1,4)"),
@@ -43,4 +56,4 @@ def test_plans_that_are_refused(ng):
         ng.plan_describe(0, 10, 4)
     # explicit overrides reach the plan
     assert "splits(h,w)=(3,5)" in ng.plan_describe(2048, 2048, 64, 1, nsplit_h=3, nsplit_w=5, split_kernel=1)
-    assert ng.plan_describe(1024, 4096, 64, 1, split_kernel=-1).startswith("fused_step_kernel_k16<NB=1>")
+    assert ng.plan_describe(1024, 4096, 64, 1, split_kernel=-1).startswith("fused_step_kernel_k16<KT=4>")

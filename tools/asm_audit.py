@@ -28,7 +28,11 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nmf-gpu_amd", "csrc")
-UNITS = ["nmf_fused16", "nmf_pair16", "nmf_split16", "nmf_fused32", "nmf_kernels", "nmf_gemm"]
+# (label, source, extra flags): the instantiations of the 64-column and of the split kernel are one source each, compiled in four
+# groups (csrc/Makefile)
+UNITS = [(f"nmf_fused16_inst{g}", "nmf_fused16_inst", (f"-DNMF_K16_GROUP={g}",)) for g in range(4)] + \
+        [(f"nmf_split16_inst{g}", "nmf_split16_inst", (f"-DNMF_S16_GROUP={g}",)) for g in range(4)] + \
+        [(u, u, ()) for u in ("nmf_fused16", "nmf_pair16", "nmf_split16", "nmf_fused32", "nmf_kernels", "nmf_gemm")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950",
          "-mllvm", "-enable-misched=false", "-mllvm", "-pragma-unroll-threshold=1000000"]   # csrc/Makefile: CXXFLAGS + KFLAGS
@@ -36,9 +40,10 @@ OPERAND_WAIT = 2          # VALU write -> MFMA A/B/C read
 RESULT_WAIT = {"16x16x4": 12, "32x32x2": 20}   # passes + 4
 
 
-def compile_unit(unit, outdir, extra=(), suffix=""):
-    out = os.path.join(outdir, unit + suffix + ".s")
-    subprocess.run([HIPCC] + FLAGS + list(extra) + ["--cuda-device-only", "-S", os.path.join(CSRC, unit + ".hip"), "-o", out],
+def compile_unit(unit, outdir):
+    label, source, extra = unit
+    out = os.path.join(outdir, label + ".s")
+    subprocess.run([HIPCC] + FLAGS + list(extra) + ["--cuda-device-only", "-S", os.path.join(CSRC, source + ".hip"), "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     return out
 
@@ -131,6 +136,11 @@ def parse_kernels(path):
             lab = m.group(1)
             if lab.startswith("_Z") and cur is None:
                 name, cur, pending = lab, [], []
+            elif lab.startswith(".Lfunc_end") and cur is not None:
+                # the end of the function, not the first s_endpgm: a kernel with an early exit (the split kernel's inactive
+                # pairs) has several, and its main body follows the first
+                kernels[name] = cur
+                cur, name = None, None
             elif cur is not None:
                 pending.append(lab)
             continue
@@ -147,9 +157,8 @@ def parse_kernels(path):
         ins = Ins(op, ops, ln, in_asm)
         ins.labels, pending = pending, []
         cur.append(ins)
-        if op == "s_endpgm":
-            kernels[name] = cur
-            cur, name = None, None
+    if cur is not None:      # hand-written snippets (self_test) carry no .Lfunc_end label
+        kernels[name] = cur
     return kernels
 
 
@@ -259,10 +268,10 @@ def run(outdir=None, report=None):
         tmp = tempfile.TemporaryDirectory()
         outdir = tmp.name
     os.makedirs(outdir, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         paths = list(ex.map(lambda u: compile_unit(u, outdir), UNITS))
     all_hazards, rows, n_asm_total = [], [], 0
-    for unit, path in zip(UNITS, paths):
+    for (unit, _, _), path in zip(UNITS, paths):
         kernels = parse_kernels(path)
         res = resources(path)
         pretty = demangle(list(kernels))
@@ -280,7 +289,7 @@ def run(outdir=None, report=None):
                          r.get(".group_segment_fixed_size", "?"), scratch, spill, n_mfma, n_asm))
     if report:
         with open(report, "w") as f:
-            f.write("# r03 kernel resources and inline-asm MFMA audit (tools/asm_audit.py; hipcc -S with the Makefile's flags, gfx950)\n\n")
+            f.write("# kernel resources and inline-asm MFMA audit (tools/asm_audit.py; hipcc -S with the Makefile's flags, gfx950)\n\n")
             f.write("VGPR / AGPR / SGPR counts, static LDS bytes (the fused kernels add dynamic LDS at launch), scratch bytes, spilled registers, MFMA "
                     "instructions in the kernel's code, and how many of those sit inside `asm volatile` statements.  Every asm MFMA was checked for a VALU "
                     f"write of one of its operands within {OPERAND_WAIT} wait states before it and for any non-accumulating touch of its result within "

@@ -1,8 +1,17 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs (one directory per counter group) into markdown tables.
-    python tools/pmc_summary.py gpurun_out/pmc6_fetch gpurun_out/pmc6_write gpurun_out/pmc6_sq gpurun_out/pmc6_insts
-Per kernel name: mean counter value per dispatch (and mean duration from the dispatch timestamps)."""
-import csv, glob, os, sys
+    python tools/pmc_summary.py [--json profiles/pmc_static.json --shape 4096x65536x256 --source "..."] DIR [DIR ...]
+Per kernel name: mean counter value per dispatch (and mean duration from the dispatch timestamps).
+--json: also merge {shape: {hbm_bytes_per_launch: {H, W}, mfma_busy_frac_of_simd_cycles: {H, W}, source}} for the half-step kernels of
+this run into the given file -- what bench.py reports as roofline.traffic (it does not collect counters itself)."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
+
+opt = {}
+argv = sys.argv[1:]
+while argv and argv[0].startswith("--"):
+    opt[argv[0][2:]] = argv[1]
+    argv = argv[2:]
+sys.argv[1:] = argv
 
 val = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> values
 dur = defaultdict(list)
@@ -43,3 +52,35 @@ for k in sorted(ks):
     mf, va = mean(c["SQ_INSTS_MFMA"]), mean(c["SQ_INSTS_VALU"])
     print(f"* `{k.split('(')[0]}`: MFMA {mf:.3e}, VALU incl. MFMA {va:.3e} (non-MFMA VALU per MFMA: {(va - mf) / mf:.2f}), LDS {mean(c['SQ_INSTS_LDS']):.3e},"
           f" VMEM {mean(c['SQ_INSTS_VMEM']):.3e}, SALU {mean(c['SQ_INSTS_SALU']):.3e}")
+
+
+def half_step(k):
+    """'H' / 'W' for a half-step instantiation (CHECK and GEMM modes excluded), else None"""
+    m = re.search(r"nmf::(fused_step_kernel_k16|split_step_kernel_k16|fused_step_kernel_pair|fused_step_kernel_v3)<([^>]*)>", k)
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(2).split(",")]
+    if m.group(1) == "split_step_kernel_k16":
+        return "W" if a[2] == "true" else "H"
+    if (m.group(1) == "fused_step_kernel_k16" and (a[4] == "true" or a[6] == "true")) or (m.group(1) == "fused_step_kernel_pair" and a[4] == "true"):
+        return None
+    if m.group(1) == "fused_step_kernel_v3" and len(a) > 5 and a[5] == "true":
+        return None
+    return "W" if a[1] == "true" else "H"
+
+
+if "json" in opt:
+    entry = {"source": opt.get("source", "rocprofv3 --pmc passes (tools/pmc_summary.py)"), "hbm_bytes_per_launch": {}, "mfma_busy_frac_of_simd_cycles": {}, "kernel": {}}
+    for k in sorted(ks):
+        hw, c = half_step(k), val[k]
+        if hw and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            entry["hbm_bytes_per_launch"][hw] = (2 * mean(c["FETCH_SIZE"]) + mean(c["WRITE_SIZE"])) * 1024
+            entry["kernel"][hw] = k.split("(")[0].replace("void ", "")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                entry["mfma_busy_frac_of_simd_cycles"][hw] = mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (mean(c["GRBM_GUI_ACTIVE"]) / 8 * 1024)
+    try:
+        allv = json.load(open(opt["json"]))
+    except Exception:
+        allv = {}
+    allv[opt["shape"]] = entry
+    json.dump(allv, open(opt["json"], "w"), indent=1, sort_keys=True)

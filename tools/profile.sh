@@ -1,9 +1,11 @@
 #!/bin/bash
-# Regenerates what profiles/r03_* holds: the bench line, its rocprofv3 kernel-trace stats, the PMC passes of the same command,
-# small-shape bench lines + timelines, the batched-restart numbers.   gpurun -- 'bash tools/r03_profile.sh [stage ...]'
+# Regenerates what profiles/rNN_* holds: the bench line, its rocprofv3 kernel-trace stats, the PMC passes of the same command,
+# small-shape bench lines + timelines, the batched-restart numbers, the true-K shape sweep.
+#   gpurun -- 'ROUND=r04 bash tools/profile.sh [stage ...]'      (output under gpurun_out/$ROUND_profile; copy what is to be kept to profiles/)
 cd /root/repo
 export TMPDIR=/tmp
-out=gpurun_out/r03_profile
+ROUND=${ROUND:-r04}
+out=gpurun_out/${ROUND}_profile
 mkdir -p $out
 stages=${@:-bench kstats pmc small restarts shapes}
 for st in $stages; do case $st in
@@ -18,9 +20,10 @@ pmc)
     timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline > $out/pmc_$name.log 2>&1
     echo "pmc $name done"
   done
-  python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_insts > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
+  python3 tools/pmc_summary.py --json $out/pmc_static.json --shape 4096x65536x256 --source "profiles/${ROUND}_pmc_summary.md: rocprofv3 --pmc passes of \`python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline\` (FETCH_SIZE x 2 + WRITE_SIZE; not this run)" \
+      $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_insts > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
 small)
-  for pr in cfg2 gold paper; do
+  for pr in cfg2 gold gold100 gold200 paper; do
     timeout -k 10 120 python3 bench.py --preset $pr --steps 200 --warmup 41 --cpu-budget 4 > $out/bench_$pr.json 2> $out/bench_$pr.err; cut -c100-330 $out/bench_$pr.json
   done
   timeout -k 10 120 python3 tools/small_bench.py > $out/small_bench.log 2>&1; cat $out/small_bench.log
@@ -33,6 +36,7 @@ restarts)
   NMF_RESTART_TRACE=1 timeout -k 10 200 python3 tools/restart_bench.py > $out/restart_bench.log 2>&1; grep -v "nmf restarts" $out/restart_bench.log
   timeout -k 10 200 python3 tools/restart_split_sweep.py > $out/restart_sweep.log 2>&1; grep "whole call\|nsplit_h=0 nsplit_w=0" $out/restart_sweep.log ;;
 shapes)
-  timeout -k 10 300 python3 tools/shape_bench.py 4096x65536x64 4096x65536x128 4096x65536x256 8192x16384x512 4096x65536x640 4096x65536x1024 4096x262144x256 > $out/shape_bench.log 2>&1; cat $out/shape_bench.log ;;
+  timeout -k 10 600 python3 tools/shape_bench.py 4096x65536x48 4096x65536x64 4096x65536x96 4096x65536x100 4096x65536x128 4096x65536x160 4096x65536x192 4096x65536x200 4096x65536x224 4096x65536x256 \
+      4096x65536x300 8192x16384x512 4096x65536x640 4096x65536x1024 4096x262144x256 > $out/shape_bench.log 2>&1; cat $out/shape_bench.log ;;
 esac; done
 find $out -name "*_agent_info.csv" -delete
