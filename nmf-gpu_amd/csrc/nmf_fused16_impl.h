@@ -40,10 +40,11 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr int N1 = 4 * KT;       // product-1 steps per 16-row tile
     constexpr int NT = KT;           // 16 x 16 accumulator tiles
     constexpr int NF = 16 * (KT / 4);   // product-1 steps in whole 64-blocks of k
-    constexpr int RR = (K % 64) / 4;    // run length per lane group in the remainder block (0, 4, 8, 12)
+    constexpr int RR = (K % 64) / 4;    // product-1 steps in the remainder block (0, 4, 8, 12): step s' covers k = 64 (K / 64) + 4 s' + kq
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
-    const int pq = ((kq & 1) << 1) | (kq >> 1);   // pi(kq)
+    // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
+    const int n1_run = N1 - (RR > 0 ? a.p1_trim : 0);
     const int P = WSTEP ? a.Np : a.Mp;
     const int Q = WSTEP ? a.Mp : a.Np;
     const int nsplit = a.nsplit;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     int q0 = (qblk * 4 + wave) * 16;
     const bool active = q0 < Q;
     if (!active) q0 = Q - 16;
-    const size_t pair = CHECK ? (size_t)blockIdx.y : 0;   // the check of a batched solver: one launch over all its pairs (FusedArgs::strideW)
+    const size_t pair = GEMM ? 0 : (size_t)blockIdx.y;   // pair of a batched solver: one launch over all of them (FusedArgs::strideW, batch)
+    if (!CHECK && !GEMM && a.active != nullptr && a.active[pair] == 0) return;   // this pair has converged (uniform: ahead of every barrier)
     const float *__restrict__ V = (WSTEP ? a.H : a.W) + pair * (WSTEP ? a.strideH : a.strideW);
     const float *__restrict__ U = (WSTEP ? a.W : a.H) + pair * (WSTEP ? a.strideW : a.strideH);
     const long ldv = WSTEP ? a.Kp : a.Mp, ldu = WSTEP ? a.Mp : a.Kp, ldx = a.Mp;
@@ -73,17 +75,14 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
                 ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
             }
-        if (RR > 0) {   // the remainder block: a run of RR (a multiple of 4: 16-B aligned) at 64 (K / 64) + RR pi(kq)
-            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + RR * pq) + (size_t)(q0 + j) * ldu;
+        if (RR > 0) {   // the remainder block is interleaved over the lane groups: one dword per step
+            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + kq) + (size_t)(q0 + j) * ldu;
 #pragma unroll
-            for (int e4 = 0; e4 < RR / 4; ++e4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(colr + 4 * e4);
-                ub[NF + 4 * e4] = v[0]; ub[NF + 4 * e4 + 1] = v[1]; ub[NF + 4 * e4 + 2] = v[2]; ub[NF + 4 * e4 + 3] = v[3];
-            }
+            for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? RR * pq : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? kq : 16 * kq)) * ldu];
     }
 
     f32x4 acc[NT];
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         float *xt_w = WSTEP ? xt + (lane >> 2) * 20 + 4 * (lane & 3) : xt + (lane >> 3) * kXtLd + 4 * (lane & 7);
         const float *xt_r = WSTEP ? xt + 4 * kq * 20 + j : xt + j * kXtLd + 4 * kq;
         const int p1_off = 16 * kq * kLdv + j;     // + k16_kconst(s) * kLdv + 16 T
-        const int p1r_off = RR * pq * kLdv + j;    // the same for the steps of the remainder block
+        const int p1r_off = kq * kLdv + j;         // the same for the steps of the remainder block
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
         f32x4 st[NST];
@@ -193,45 +192,67 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             f32x4 s0, s1;
             constexpr int NLOAD = NST + 2;
             constexpr int G = E1 / (NLOAD + 1);
-#pragma unroll
-            for (int e = 0; e < E1; ++e) {
-                const int s = e >> 1;
-                if (KT > 24) {
-                    // K > 384 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
-                    // in front of it and its hazard recogniser cannot see into the asm (nmf_split16.hip, K = 256, came out ~1 % wrong
-                    // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
-                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
-                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
+            // Position e = 2 s + T of the chain: its MFMA (if COND), then what rides along with it -- the operand ring, the staging of the
+            // next chunk.  A macro, not a lambda: with the body behind a by-reference closure the register allocator spilled (K = 240, 256).
+            // K > 384 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
+            // in front of it and its hazard recogniser cannot see into the asm (nmf_split16.hip, K = 256, came out ~1 % wrong
+            // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
+            // K % 64 != 0: the chain ends in a branch (p1_trim) and the two arms may keep s0 / s1 in different registers: the
+            // copies at the join sit next to the chain's last MFMAs (tools/asm_audit.py flagged every such kernel with asm MFMAs).
+            // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
+            // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: the last 8 NST steps,
+            // which is the second half exactly where KT is even)
+            // (the check also fetches the next X tile, first: it is used first)
+#define NMF_P1_POSITION(e, COND)                                                                                                                     \
+                {                                                                                                                    \
+                    const int s = (e) >> 1;                                                                                          \
+                    if (COND) {                                                                                                      \
+                    if (KT > 24 || RR > 0) {                                                                                         \
+                        if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
+                        else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
+                        else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
+                        else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);                                                      \
+                    }                                                                                                                \
+                    else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));       \
+                    else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));       \
+                    else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));  \
+                    else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));  \
+                    }                                                                                                                \
+                    if (e + D < E1) ar[e % D] = a1_ld(e + D);                                                                        \
+                    if (GEMM || CHECK) {                                                                                             \
+                        constexpr int NLD = GEMM ? NST : NST + 2;                                                                    \
+                        constexpr int GL = (E1 / 2) / (NLD + 1) > 0 ? (E1 / 2) / (NLD + 1) : 1;                                      \
+                        constexpr int ES = E1 - 8 * NST;                                                                             \
+                        if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {                                                            \
+                            const int l = e / GL - 1;                                                                                \
+                            if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);                  \
+                            __builtin_amdgcn_sched_barrier(0);                                                                       \
+                        }                                                                                                            \
+                        if (e >= ES && (e - ES) % 2 == 0 && (e - ES) / 2 < 4 * NST) {                                                \
+                            stage_store_one(vn, (e - ES) / 2);                                                                       \
+                            __builtin_amdgcn_sched_barrier(0);                                                                       \
+                        }                                                                                                            \
+                    } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {                                                          \
+                        const int l = e / G - 1;                                                                                     \
+                        if (l < 2) x_load_one(l); else stage_load_one(l - 2);                                                        \
+                        __builtin_amdgcn_sched_barrier(0);                                                                           \
+                    }                                                                                                                \
                 }
-                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
-                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
-                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
-                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
-                if (e + D < E1) ar[e % D] = a1_ld(e + D);
-                if (GEMM || CHECK) {
-                    // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
-                    // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: the last 8 NST steps,
-                    // which is the second half exactly where KT is even)
-                    constexpr int NLD = GEMM ? NST : NST + 2;   // the check also fetches the next X tile (first: it is used first)
-                    constexpr int GL = (E1 / 2) / (NLD + 1) > 0 ? (E1 / 2) / (NLD + 1) : 1;
-                    constexpr int ES = E1 - 8 * NST;
-                    if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {
-                        const int l = e / GL - 1;
-                        if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (e >= ES && (e - ES) % 2 == 0 && (e - ES) / 2 < 4 * NST) {
-                        stage_store_one(vn, (e - ES) / 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
-                    const int l = e / G - 1;
-                    if (l < 2) x_load_one(l); else stage_load_one(l - 2);
-                    __builtin_amdgcn_sched_barrier(0);
+            // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
+            // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
+            constexpr int ET = RR > 0 ? E1 - 6 : E1;
+#pragma unroll
+            for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
+            if (RR > 0) {
+                if (n1_run == N1) {
+#pragma unroll
+                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)
+                } else {
+#pragma unroll
+                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, ((e) >> 1) < n1_run)
                 }
             }
+#undef NMF_P1_POSITION
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             if (GEMM) {   // lane holds S(p0 + 16 T + 4 kq + r, q0 + j): two 16-B stores per chunk, 64 B contiguous per column and half
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         if (vsum_on) {
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) vs_acc += __shfl_down(vs_acc, off, 32);
-            if (lane == 0 && vrow_raw < KS) a.vsum_part[(size_t)split * KS + vrow_raw] = vs_acc;
+            if (lane == 0 && vrow_raw < KS) a.vsum_part[(pair * nsplit + (size_t)split) * KS + vrow_raw] = vs_acc;
         }
     }
     if (CHECK) {
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     // epilogue: lane holds Acc(k = 16 t + 4 kq + r, q0 + j)
     if (PARTIAL) {
         const size_t slab = WSTEP ? (size_t)a.Mp * a.Kp : (size_t)a.Kp * a.Np;
-        float *__restrict__ out = a.partials + (size_t)split * slab;
+        float *__restrict__ out = a.partials + (pair * nsplit + (size_t)split) * slab;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (!WSTEP) *reinterpret_cast<f32x4 *>(out + (size_t)(16 * t + 4 * kq) + (size_t)(q0 + j) * ldu) = acc[t];
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             }
         }
     } else {
-        float *__restrict__ Uo = a.U_out;
-        const float *__restrict__ nrm = a.norm;
+        float *__restrict__ Uo = a.U_out + pair * (WSTEP ? a.strideW : a.strideH);
+        const float *__restrict__ nrm = a.norm + pair * KS;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = 16 * t + 4 * kq;
@@ -359,7 +380,8 @@ template <int KT>
 hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) {
     constexpr int OCC = k16_occ<KT>();
     const int Q = wstep ? a.Mp : a.Np;
-    const dim3 grid((unsigned)(((Q + 63) / 64) * a.nsplit)), block(256);
+    if (a.batch < 1 || a.batch > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(((Q + 63) / 64) * a.nsplit), (unsigned)a.batch), block(256);
     const size_t lds = k16_lds_bytes<KT>();
     const bool partial = a.partial != 0;
     const bool fast = fused_fast_divide() || a.fast_divide;

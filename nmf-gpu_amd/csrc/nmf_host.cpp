@@ -102,6 +102,7 @@ static double now_s() {
 struct nmf_solver {
     int M = 0, N = 0, K = 0;       // logical (local) dims
     int Mp = 0, Np = 0, Kp = 0;    // padded device dims
+    int p1_trim = 0;               // 16-column kernels, Kc % 64 != 0: steps of product 1 skipped because they cover zero padding only: (Kc - pad4(K)) / 4
     int Kc = 0;                    // the K the chosen kernel computes on: a multiple of 16, <= Kp (FusedArgs::Kc / SplitArgs::Kc); the rest of Kp is zero padding
     int path = NMF_PATH_FUSED;
     int use_graph = 1;
@@ -220,12 +221,13 @@ void release_stream(hipStream_t st) {
 // launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
 constexpr int kMaxRowsApplyColsum = 65536;
 
-static int pick_nsplit(int q_extent, int p_extent, int q_per_group) {
-    // workgroups per split-less launch = ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU),
-    // keep >= 2 chunks of 32 per split.
-    const int nq = (q_extent + q_per_group - 1) / q_per_group;
+static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch = 1) {
+    // workgroups per split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU),
+    // keep >= 2 chunks of 32 per split.  A launch that carries `batch` pairs (restarts) hands out batch times the workgroups:
+    // the split shrinks with it (fewer slabs, shorter apply), as on the split kernel (pick_split).
+    const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
     if (nq >= 256) return 1;
-    int ns = (512 + nq - 1) / nq;
+    int ns = (int)((512 + nq - 1) / nq);
     const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
     if (ns > max_ns) ns = max_ns;
     if (ns > 64) ns = 64;
@@ -314,7 +316,6 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // the split kernel streams whole superchunks of 128: zero padding is invariant under the updates and adds nothing to any sum
     s->Mp = s->split ? ((M + 127) & ~127) : pad32(M);
     s->Np = s->split ? ((N + 127) & ~127) : pad32(N);
-    if (batch > 1 && !s->split) { set_err("batched solvers need the split kernel (K <= 256)"); return NMF_ERR_UNSUPPORTED; }
     if (s->split) path = NMF_PATH_FUSED;
     // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
     const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
@@ -330,6 +331,17 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         s->Kc = s->Kp;
     }
     s->path = path;
+    // product 1 of the 16-column kernels steps through K four at a time: the steps beyond pad4(K) hold zero padding only
+    s->p1_trim = 0;
+    if (path == NMF_PATH_FUSED && s->Kc >= 32 && s->Kc <= 512 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
+    if (s->p1_trim > 3) s->p1_trim = 3;
+    if (getenv("NMF_NO_P1_TRIM")) s->p1_trim = 0;
+    // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
+    // (blockIdx.y = pair: nmf_fused16_impl.h); the 32-column and the wave-pair kernels and the operator path take one pair
+    if (batch > 1 && !s->split && !(path == NMF_PATH_FUSED && fused_takes_batch(s->Kp) && s->Mp <= kMaxRowsApplyColsum)) {
+        set_err("batched solvers need the split kernel or the 64-column kernel (32 < K <= 512, M <= 65536)");
+        return NMF_ERR_UNSUPPORTED;
+    }
     s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
     s->fast_divide = o.fast_divide;
     if (s->split) {
@@ -352,8 +364,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         s->chk_groups = check_num_groups(s->Np, s->Kp);
     } else if (path == NMF_PATH_FUSED) {
         const int qg = fused_cols_per_group(s->Kp);
-        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg);
-        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg);
+        const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call: a restart gets the same splits wherever it runs
+        s->split_batch = sb;
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
         s->chk_groups = check_num_groups(s->Np, s->Kp);
@@ -390,9 +404,9 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     ar.reserve((void **)&s->H, kn * batch * sizeof(float), true);
     if (x_from) { s->X = x_from->X; s->x_shared = true; s->x_in_range = x_from->x_in_range; }   // read-only, already uploaded
     else ar.reserve((void **)&s->X, mn * sizeof(float), true);
-    ar.reserve((void **)&s->normW, ((size_t)s->Kp) * sizeof(float));
-    ar.reserve((void **)&s->normH, ((size_t)s->Kp) * sizeof(float));
-    ar.reserve((void **)&s->rowpart, ((size_t)row_sum_blocks(s->Np) * s->Kp) * sizeof(float));
+    ar.reserve((void **)&s->normW, ((size_t)s->Kp * batch) * sizeof(float));
+    ar.reserve((void **)&s->normH, ((size_t)s->Kp * batch) * sizeof(float));
+    ar.reserve((void **)&s->rowpart, ((size_t)row_sum_blocks(s->Np) * s->Kp * (s->split ? 1 : batch)) * sizeof(float));
     ar.reserve((void **)&s->psum_owned, (mk + (size_t)s->Kp) * sizeof(float));
     if (s->split) {
         size_t pc = (s->ns_w > 1 || batch == 1) ? (size_t)s->ns_w * mk : 0;   // an unbatched solver's W-step may always need slabs (sharded runs)
@@ -404,9 +418,9 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     } else if (path == NMF_PATH_FUSED) {
         size_t pc = 0;
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
-        if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded)
-        ar.reserve((void **)&s->partials, (pc) * sizeof(float));
-        if (s->nsplit_w > 1 && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp) * sizeof(float));
+        if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded; a batch: always)
+        ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
+        if ((s->nsplit_w > 1 || batch > 1) && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp * batch) * sizeof(float));
     } else {
         ar.reserve((void **)&s->Z, (mn) * sizeof(float));
         ar.reserve((void **)&s->WtZ, (kn) * sizeof(float));
@@ -545,7 +559,7 @@ extern "C" int nmf_solver_batch(const nmf_solver *s) { return s ? s->batch : 0; 
 extern "C" int nmf_solver_uses_split_kernel(const nmf_solver *s) { return (s && s->split) ? 1 : 0; }
 extern "C" int nmf_solver_upload_pair(nmf_solver *s, int b, const float *W, const float *H) {
     if (!s || b < 0 || b >= s->batch) return NMF_ERR_ARG;
-    if (b == 0) s->normW_fresh = false;
+    s->normW_fresh = false;
     NMFCHK(upload_one(s, s->W + (size_t)b * s->Mp * s->Kp, s->Mp, s->Kp, W, s->M, s->K, true));
     NMFCHK(upload_one(s, s->H + (size_t)b * s->Kp * s->Np, s->Kp, s->Np, H, s->K, s->N, true));
     return NMF_OK;
@@ -700,8 +714,9 @@ static FusedArgs fused_args(nmf_solver *s) {
     FusedArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.norm = nullptr;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide > 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.p1_trim = s->p1_trim; a.nsplit = 1; a.partial = 0; a.fast_divide = s->fast_divide > 0;
     a.x_in_range = s->fast_divide < 0 ? 0 : s->x_in_range;
+    a.batch = s->batch; a.strideW = (size_t)s->Mp * s->Kp; a.strideH = (size_t)s->Kp * s->Np; a.active = s->active_d;
     return a;
 }
 
@@ -709,7 +724,7 @@ static SplitArgs split_args(nmf_solver *s) {
     SplitArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.p1_trim = s->p1_trim; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
     a.nw_h = s->nw_h; a.nw_w = s->nw_w;
     // 64 < K <= 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
     const bool mid_k = s->Kp > 64 && s->Kp <= 128;
@@ -748,7 +763,7 @@ static int enqueue_update_h(nmf_solver *s) {
     hipStream_t st = s->stream;
     if (s->split) return enqueue_split_h(s);
     if (s->path == NMF_PATH_FUSED) {
-        if (!s->normW_fresh) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st)); }
+        if (!s->normW_fresh) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, st, s->batch, (size_t)s->Mp * s->Kp)); }
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_h;
         if (s->nsplit_h == 1) {
@@ -759,7 +774,7 @@ static int enqueue_update_h(nmf_solver *s) {
             a.partial = 1;
             { PieceScope p(s, NMF_T_H_STEP); HIPCHK(launch_fused_step(a, false, st)); }
             PieceScope p(s, NMF_T_APPLY);
-            HIPCHK(launch_apply_partials(s->H, s->partials, s->nsplit_h, s->normW, s->Mp, s->Np, s->Kp, false, st));
+            HIPCHK(launch_apply_partials(s->H, s->partials, s->nsplit_h, s->normW, s->Mp, s->Np, s->Kp, false, st, nullptr, s->batch, a.strideH, s->active_d));
         }
         return NMF_OK;
     }
@@ -851,6 +866,18 @@ static int enqueue_update_w(nmf_solver *s) {
     if (s->path == NMF_PATH_FUSED) {
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_w;
+        if (s->batch > 1) {
+            // every pair in one launch: raw slabs (also with nsplit_w == 1), finished per pair by the apply that also leaves the next
+            // H-step's normaliser.  The row sums of H come off the stream where the W-step's workgroups cover all K rows (K <= M / 16:
+            // no row-sum launches), else from the two-level row-sum kernels with a pair dimension.
+            a.partial = 1; a.vsum_part = s->vsum_part;
+            if (!s->vsum_part) { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st, s->batch, a.strideH)); }
+            { PieceScope p(s, NMF_T_W_STEP); HIPCHK(launch_fused_step(a, true, st)); }
+            PieceScope p(s, NMF_T_APPLY);
+            HIPCHK(launch_apply_w_colsum(s->W, s->partials, s->nsplit_w, s->vsum_part ? nullptr : s->normH, s->vsum_part, s->Mp, s->Kp, s->normW, st, s->batch, a.strideW, s->active_d));
+            s->normW_fresh = true;
+            return NMF_OK;
+        }
         if (s->nsplit_w == 1) {
             { PieceScope p(s, NMF_T_SUMS); HIPCHK(launch_row_sums(s->H, s->Kp, s->Np, s->Kp, s->rowpart, s->normH, true, st)); }
             a.U_out = s->W; a.norm = s->normH; a.partial = 0;
@@ -976,7 +1003,7 @@ static int ensure_level(nmf_solver *s, int li) {
 static bool w_step_refreshes_normW(const nmf_solver *s) {
     if (s->Mp > kMaxRowsApplyColsum) return false;
     if (s->split) return false;   // the split kernel sums its normaliser from the factor it streams
-    return s->comm ? true : (s->path == NMF_PATH_FUSED && s->nsplit_w > 1);
+    return s->comm ? true : (s->path == NMF_PATH_FUSED && (s->nsplit_w > 1 || s->batch > 1));
 }
 
 extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
@@ -988,7 +1015,7 @@ extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
         // column-sum launch and the very first H-step needs one made here; elsewhere every captured H-step brings its own.
         const bool lean = w_step_refreshes_normW(s);
         if (lean && !s->normW_fresh) {
-            HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, s->stream));
+            HIPCHK(launch_col_sums(s->W, s->Mp, s->Kp, s->Mp, s->normW, true, s->stream, s->batch, (size_t)s->Mp * s->Kp));
             s->normW_fresh = true;
         }
         if (!lean) s->normW_fresh = false;
@@ -1537,12 +1564,25 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
     return st;
 }
 
+// Do the restarts of this shape run as ONE batched solver (the restart index a grid dimension)?  Shapes the split kernel takes:
+// always.  Shapes of the 64-column kernel: where a lone pair's launch leaves CUs idle or needs partial slabs to fill them --
+// fewer than 512 column groups in the H-step (N < 32768) -- e.g. 4096 x 4096 x 256, 2048 x 8192 x 512; above that one launch
+// fills the chip by itself and the restarts run one after the other (auto_lanes).
+static bool restarts_take_batch(int M, int N, int K, const nmf_opts &o) {
+    if (want_split(M, N, K, o)) return true;
+    if (o.path == NMF_PATH_UNFUSED || o.split_kernel > 0) return false;
+    const int kp = fused_pad_k(K), Mp = pad32(M), Np = pad32(N);
+    if (!kp || !fused_takes_batch(kp) || Mp > kMaxRowsApplyColsum || (size_t)kp * (size_t)Mp >= ((size_t)1 << 31)) return false;
+    return (Np + 63) / 64 < 512;
+}
+
 // all restarts of `W`, `H` on ONE device (o.device, or the current one); split_batch: restart count of the whole call
 static int restarts_one_device(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
-    // restart_lanes > 0 asks for the stream-lane mechanism explicitly (the shapes the split kernel does not take use it anyway)
-    if (n_restarts > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o)) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch, gidx);
-    if (n_restarts == 1 && split_batch > 1 && o.restart_lanes <= 0 && !o.comm && want_split(M, N, K, o))   // this device's share of a batched call
+    // restart_lanes > 0 asks for the stream-lane mechanism explicitly (the shapes no batched kernel takes use it anyway)
+    const bool batched = o.restart_lanes <= 0 && !o.comm && restarts_take_batch(M, N, K, o);
+    if (n_restarts > 1 && batched) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch, gidx);
+    if (n_restarts == 1 && split_batch > 1 && batched)   // this device's share of a batched call
         return restarts_batched(W, H, 1, X, o, M, N, K, best, kl, split_batch, gidx);
     std::vector<nmf_solver *> lane;
     nmf_solver *s0 = nullptr;

@@ -34,14 +34,19 @@ struct FusedArgs {
     int Mp, Np, Kp;
     int Kc = 0;               // 16-column kernel: the K its MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (rows / columns Kc .. Kp - 1 of
                               //    the factors are zero padding); 0 = Kp.  The other families compute on Kp.
+    int p1_trim = 0;          // 16-column kernel, Kc % 64 != 0: the last p1_trim (0 .. 3) steps of product 1 cover zero padding only (the
+                              //    caller's K <= Kc - 4 p1_trim) and are skipped: product 1 at a granularity of 4 in K (nmf_device.h)
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
     int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
     int x_in_range;           // 1: every entry of X is 0 or in [EPS, 2^60] (checked at upload): the 16-column kernel may
                               //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
-    // CHECK instantiations only: blockIdx.y = pair of a batched solver (W, H of pair b at + b * strideW / strideH floats; its
-    // partial triples behind those of pair b - 1): nmf_solver_check_all evaluates every pair's check in ONE launch
+    // blockIdx.y = pair of a batched solver (16-column kernel only): W, H of pair b at + b * strideW / strideH floats; its slabs
+    // ([nsplit] of them), normalisers (Kp) and vsum_part rows ([nsplit][Kp]) behind those of pair b - 1; the CHECK instantiation's
+    // partial triples likewise (nmf_solver_check_all evaluates every pair's check in ONE launch).  batch = gridDim.y.
     size_t strideW = 0, strideH = 0;
+    int batch = 1;
+    const int *active = nullptr;  // optional [batch] flags: 0 = leave this pair untouched (it has converged)
     float *vsum_part = nullptr;   // optional, W-step with partial slabs on the 16-column kernel (fused_streams_vsum()): nsplit x Kp
                               //    floats receiving, per split, the row sums of the streamed factor H over that split's columns
                               //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
@@ -84,6 +89,7 @@ struct SplitArgs {
     float *vpart;             // nsplit  > 1
     int Mp, Np, Kp;
     int Kc = 0;               // the K the MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (split_compute_k); 0 = Kp
+    int p1_trim = 0;          // as FusedArgs::p1_trim
     int Mv, Nv;               // M, N rounded up to 32: column groups beyond them hold only zero padding and get no workgroup
     int nsplit;
     int nw_h, nw_w;           // waves per workgroup (4 or 8) of the H- and the W-step: reduction length % (32 nw) == 0; 8 needs Kp == 64
@@ -104,12 +110,14 @@ hipError_t launch_split_apply(float *U, const float *partials, const float *vpar
 
 // U[k,q] *= (sum_s partials[s][k,q]) / norm[k]   (col_div/row_div + vec_mul, cuda/matrix.cu:174-250)
 // norm == nullptr (W-step only): the normaliser is max(sum_s vsum_part[s][k], EPS) instead
+// batch > 1: pair b's factor at U + b * ustride, its slabs, normalisers and vsum_part rows behind those of pair b - 1 (FusedArgs)
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm,
-                                 int Mp, int Np, int Kp, bool wstep, hipStream_t stream, const float *vsum_part = nullptr);
+                                 int Mp, int Np, int Kp, bool wstep, hipStream_t stream, const float *vsum_part = nullptr,
+                                 int batch = 1, size_t ustride = 0, const int *active = nullptr);
 // W-step apply that also leaves norm_out[k] = max(colsum(W_new)[k], EPS), the next H-step's normaliser (sum_cols + set_epsilon,
 // cuda/nmf.cu:134-135): one 1024-thread workgroup per column of W.  Normaliser from norm or vsum_part as in launch_apply_partials.
 hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, const float *norm, const float *vsum_part,
-                                 int Mp, int Kp, float *norm_out, hipStream_t stream);
+                                 int Mp, int Kp, float *norm_out, hipStream_t stream, int batch = 1, size_t wstride = 0, const int *active = nullptr);
 // psum = sum_s partials[s]   (sharded W-step: operand of the all-reduce)
 // vsum_part != nullptr: also psum[count + k] = sum_s vsum_part[s][k], k < Kp (the unclamped row sums of H behind the slab sum)
 // q_valid > 0 (with Mp, the slabs' leading dimension): rows >= q_valid of every column were written by no workgroup (zero
@@ -129,6 +137,7 @@ hipError_t launch_apply_w(float *W, const float *psum, const float *hsum, int Mp
 //     order and leaves {KL, sum|X-WH|, sum|X|} in out3.
 int        check_num_groups(int Np, int Kp);
 bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
+bool       fused_takes_batch(int Kp);   // can a batched solver run this K on the 16-column kernel (blockIdx.y = pair)?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
 int        fused_pad_k(int K);             // K as the fused path pads it in HBM (a multiple of 32; of 128 above 512), 0 if the fused path cannot take it
 int        fused_compute_k(int K);         // K as the chosen fused kernel computes on it (FusedArgs::Kc): <= fused_pad_k(K), a multiple of 16
@@ -147,11 +156,13 @@ hipError_t launch_check_compose(const double *part, int ngroups, const float *W,
 
 // ---------------------------------------------------------------- normalisers
 // out[k] = max(sum_i A[i + k*ld], EPS), one workgroup per column (sum_cols + set_epsilon, cuda/nmf.cu:134-135)
-hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream);
+// batch > 1: matrix b at A + b * astride, its sums at out + b * cols
+hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream, int batch = 1, size_t astride = 0);
 // row sums in two deterministic levels: part[b][k] then out[k] = max(sum_b part[b][k], EPS) (cuda/nmf.cu:164-165)
 int        row_sum_blocks(int cols);
+// batch > 1: matrix b at A + b * astride, its block partials and sums behind those of matrix b - 1
 hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp,
-                           hipStream_t stream);
+                           hipStream_t stream, int batch = 1, size_t astride = 0);
 
 // ---------------------------------------------------------------- unfused operators
 enum GemmKind { GEMM_NN = 0, GEMM_TN = 1, GEMM_NT = 2 };

@@ -45,6 +45,7 @@ hipError_t launch_zero(void *p, size_t bytes, hipStream_t stream) {
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream) {
     if ((a.Mp | a.Np | a.Kp) & 31) return hipErrorInvalidValue;
     if (a.nsplit < 1 || (a.nsplit > 1 && !a.partial)) return hipErrorInvalidValue;
+    if (a.batch != 1 && !use_k16(a.Kp)) return hipErrorInvalidValue;   // blockIdx.y = pair exists on the 16-column kernel only
     if (use_pair(a.Kp)) return launch_fused_pair(a, wstep, stream);
     return use_k16(a.Kp) ? launch_fused16(a, wstep, stream) : launch_fused32(a, wstep, stream);
 }
@@ -65,6 +66,7 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
 
 // one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows
 bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 4 >= (size_t)Kp; }
+bool fused_takes_batch(int Kp) { return use_k16(Kp); }
 int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
 // K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 512 -- the 16-column kernel has an
 // instantiation for every multiple of 16 up to 256 and of 32 up to 512 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
@@ -88,7 +90,12 @@ int check_num_groups(int Np, int Kp) { return (Np + fused_cols_per_group(Kp) - 1
 template <bool WSTEP>
 __global__ __launch_bounds__(256) void apply_partials_kernel(float *__restrict__ U, const float *__restrict__ P, int nsplit,
                                                              const float *__restrict__ nrm, const float *__restrict__ vsum_part,
-                                                             size_t count, int Mp, int Kp) {
+                                                             size_t count, int Mp, int Kp, size_t ustride, const int *__restrict__ active) {
+    const size_t b = blockIdx.y;   // pair of a batched solver
+    if (active != nullptr && active[b] == 0) return;
+    U += b * ustride; P += b * (size_t)nsplit * count;
+    if (nrm) nrm += b * (size_t)Kp;
+    if (vsum_part) vsum_part += b * (size_t)nsplit * Kp;
     int k_cached = -1;
     float n_cached = 1.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
@@ -114,11 +121,12 @@ __global__ __launch_bounds__(256) void apply_partials_kernel(float *__restrict__
 
 
 hipError_t launch_apply_partials(float *U, const float *partials, int nsplit, const float *norm, int Mp, int Np, int Kp,
-                                 bool wstep, hipStream_t stream, const float *vsum_part) {
+                                 bool wstep, hipStream_t stream, const float *vsum_part, int batch, size_t ustride, const int *active) {
     const size_t count = wstep ? (size_t)Mp * Kp : (size_t)Kp * Np;
-    if ((!norm && !vsum_part) || (vsum_part && !wstep)) return hipErrorInvalidValue;
-    if (wstep) hipLaunchKernelGGL(apply_partials_kernel<true>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp);
-    else       hipLaunchKernelGGL(apply_partials_kernel<false>, dim3(ew_grid(count)), dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp);
+    if ((!norm && !vsum_part) || (vsum_part && !wstep) || batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    const dim3 grid(ew_grid(count), (unsigned)batch);
+    if (wstep) hipLaunchKernelGGL(apply_partials_kernel<true>, grid, dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp, ustride, active);
+    else       hipLaunchKernelGGL(apply_partials_kernel<false>, grid, dim3(256), 0, stream, U, partials, nsplit, norm, vsum_part, count, Mp, Kp, ustride, active);
     return hipGetLastError();
 }
 
@@ -140,8 +148,13 @@ __device__ __forceinline__ float column_total_1024(float partial) {
 // values, reduced in a fixed order (per-thread strided partial -> wave shuffle tree -> 16 waves), clamped, goes to norm_out[k].
 __global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict__ W, const float *__restrict__ P, int nsplit,
                                                               const float *__restrict__ nrm, const float *__restrict__ vsum_part,
-                                                              int Mp, int Kp, float *__restrict__ norm_out) {
+                                                              int Mp, int Kp, float *__restrict__ norm_out, size_t wstride, const int *__restrict__ active) {
     const int k = blockIdx.x;
+    const size_t b = blockIdx.y;   // pair of a batched solver
+    if (active != nullptr && active[b] == 0) return;
+    W += b * wstride; P += b * (size_t)nsplit * Mp * Kp; norm_out += b * (size_t)Kp;
+    if (nrm) nrm += b * (size_t)Kp;
+    if (vsum_part) vsum_part += b * (size_t)nsplit * Kp;
     float n;
     if (vsum_part) {
         n = vsum_part[k];
@@ -169,9 +182,9 @@ __global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict_
     if (threadIdx.x == 0) norm_out[k] = clamp_eps(tot);
 }
 hipError_t launch_apply_w_colsum(float *W, const float *partials, int nsplit, const float *norm, const float *vsum_part, int Mp, int Kp,
-                                 float *norm_out, hipStream_t stream) {
-    if ((!norm && !vsum_part) || !norm_out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(apply_w_colsum_kernel, dim3(Kp), dim3(1024), 0, stream, W, partials, nsplit, norm, vsum_part, Mp, Kp, norm_out);
+                                 float *norm_out, hipStream_t stream, int batch, size_t wstride, const int *active) {
+    if ((!norm && !vsum_part) || !norm_out || batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(apply_w_colsum_kernel, dim3(Kp, (unsigned)batch), dim3(1024), 0, stream, W, partials, nsplit, norm, vsum_part, Mp, Kp, norm_out, wstride, active);
     return hipGetLastError();
 }
 
@@ -333,15 +346,17 @@ hipError_t launch_kl_reduce(const float *x, const float *y, size_t n, double *pa
 // Normalisers (sum_cols / sum_rows + set_epsilon, cuda/nmf.cu:134-135, 164-165)
 // wave64 shuffle tree + LDS across the 4 waves; fixed summation order -> reproducible.
 // =====================================================================================
-__global__ __launch_bounds__(1024) void col_sums_kernel(const float *__restrict__ A, int rows, long ld, float *__restrict__ out, int clamp) {
+__global__ __launch_bounds__(1024) void col_sums_kernel(const float *__restrict__ A, int rows, long ld, float *__restrict__ out, int clamp, size_t astride) {
+    A += (size_t)blockIdx.y * astride; out += (size_t)blockIdx.y * gridDim.x;   // matrix b of a batch
     const float *__restrict__ a = A + (size_t)blockIdx.x * ld;
     float s = 0.f;
     for (int i = threadIdx.x; i < rows; i += 1024) s += a[i];
     const float tot = column_total_1024(s);
     if (threadIdx.x == 0) out[blockIdx.x] = clamp ? clamp_eps(tot) : tot;
 }
-hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream) {
-    hipLaunchKernelGGL(col_sums_kernel, dim3(cols), dim3(1024), 0, stream, A, rows, ld, out, clamp ? 1 : 0);
+hipError_t launch_col_sums(const float *A, int rows, int cols, long ld, float *out, bool clamp, hipStream_t stream, int batch, size_t astride) {
+    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(col_sums_kernel, dim3(cols, (unsigned)batch), dim3(1024), 0, stream, A, rows, ld, out, clamp ? 1 : 0, astride);
     return hipGetLastError();
 }
 
@@ -349,8 +364,9 @@ constexpr int kRowSumCols = 64;   // columns per workgroup in level 1 (>= 1024 w
 int row_sum_blocks(int cols) { return (cols + kRowSumCols - 1) / kRowSumCols; }
 
 // level 1: part[b*rows + k] = sum over this block's columns of A[k + col*ld]; fixed order per (b, k)
-__global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restrict__ A, int rows, int cols, long ld, float *__restrict__ part) {
+__global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restrict__ A, int rows, int cols, long ld, float *__restrict__ part, size_t astride) {
     __shared__ float red[256];
+    A += (size_t)blockIdx.y * astride; part += (size_t)blockIdx.y * gridDim.x * rows;   // matrix b of a batch
     const int c0 = blockIdx.x * kRowSumCols;
     const int c1 = (c0 + kRowSumCols < cols) ? c0 + kRowSumCols : cols;
     float *__restrict__ outp = part + (size_t)blockIdx.x * rows;
@@ -385,6 +401,7 @@ __global__ __launch_bounds__(256) void row_sums_l1_kernel(const float *__restric
 // over the partial blocks, then a fixed-order LDS combine.
 __global__ __launch_bounds__(1024) void row_sums_l2_kernel(const float *__restrict__ part, int rows, int nblk, float *__restrict__ out, int clamp) {
     __shared__ float red[32][33];
+    part += (size_t)blockIdx.y * nblk * rows; out += (size_t)blockIdx.y * rows;   // matrix b of a batch
     const int kl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + kl;
     float s0 = 0.f, s1 = 0.f;
@@ -401,12 +418,13 @@ __global__ __launch_bounds__(1024) void row_sums_l2_kernel(const float *__restri
         out[k] = clamp ? clamp_eps(tot) : tot;
     }
 }
-hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp, hipStream_t stream) {
+hipError_t launch_row_sums(const float *A, int rows, int cols, long ld, float *part, float *out, bool clamp, hipStream_t stream, int batch, size_t astride) {
+    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
     const int nblk = row_sum_blocks(cols);
-    hipLaunchKernelGGL(row_sums_l1_kernel, dim3(nblk), dim3(256), 0, stream, A, rows, cols, ld, part);
+    hipLaunchKernelGGL(row_sums_l1_kernel, dim3(nblk, (unsigned)batch), dim3(256), 0, stream, A, rows, cols, ld, part, astride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(row_sums_l2_kernel, dim3((rows + 31) / 32), dim3(1024), 0, stream, part, rows, nblk, out, clamp ? 1 : 0);
+    hipLaunchKernelGGL(row_sums_l2_kernel, dim3((rows + 31) / 32, (unsigned)batch), dim3(1024), 0, stream, part, rows, nblk, out, clamp ? 1 : 0);
     return hipGetLastError();
 }
 

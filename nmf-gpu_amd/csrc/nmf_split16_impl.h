@@ -52,10 +52,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
     constexpr int NT = KT;           // 16 x 16 accumulator tiles
     constexpr int NPC = 4 * NST;     // staged pieces per thread per superchunk
     constexpr int NF = 16 * (KT / 4);   // product-1 steps in whole 64-blocks of k
-    constexpr int RR = (K % 64) / 4;    // run length per lane group in the remainder block (0, 4, 8, 12)
+    constexpr int RR = (K % 64) / 4;    // product-1 steps in the remainder block (0, 4, 8, 12): step s' covers k = 64 (K / 64) + 4 s' + kq
     constexpr int D = kRing < 2 * N1 ? kRing : 2 * N1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
-    const int pq = ((kq & 1) << 1) | (kq >> 1);   // pi(kq)
+    // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
+    const int n1_run = N1 - (RR > 0 ? a.p1_trim : 0);
     const int b = blockIdx.y;
     if (a.active != nullptr && a.active[b] == 0) return;
     const int P = WSTEP ? a.Np : a.Mp;   // a multiple of 32 NW: every superchunk is whole
@@ -94,17 +95,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
                 ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
             }
-        if (RR > 0) {   // the remainder block: a run of RR (a multiple of 4: 16-B aligned) at 64 (K / 64) + RR pi(kq)
-            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + RR * pq) + (size_t)(q0 + j) * ldu;
+        if (RR > 0) {   // the remainder block is interleaved over the lane groups: one dword per step
+            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + kq) + (size_t)(q0 + j) * ldu;
 #pragma unroll
-            for (int e4 = 0; e4 < RR / 4; ++e4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(colr + 4 * e4);
-                ub[NF + 4 * e4] = v[0]; ub[NF + 4 * e4 + 1] = v[1]; ub[NF + 4 * e4 + 2] = v[2]; ub[NF + 4 * e4 + 3] = v[3];
-            }
+            for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? RR * pq : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? kq : 16 * kq)) * ldu];
     }
 
     // The values this wave will update in the epilogue (tiles t = wave, wave + NW, ...: U(16 t + 4 kq + r, q0 + j)), fetched
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         const int xw_off = WSTEP ? (lane >> 2) * 20 + 4 * (lane & 3) : (lane >> 3) * kXtLd + 4 * (lane & 7);
         const int xr_off = WSTEP ? 4 * kq * 20 + j : j * kXtLd + 4 * kq;
         const int p1_off = 16 * kq * kLdv + j;     // + k16_kconst(s) * kLdv + 16 T
-        const int p1r_off = RR * pq * kLdv + j;    // the same for the steps of the remainder block
+        const int p1r_off = kq * kLdv + j;         // the same for the steps of the remainder block
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
         f32x4 st[NPC];
@@ -274,29 +272,50 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             f32x4 s0, s1;
             constexpr int NLOAD = NPC + 2;
             constexpr int G = E1 / (NLOAD + 1);
-#pragma unroll
-            for (int e = 0; e < E1; ++e) {
-                const int s = e >> 1;
-                if (KT > 8) {
-                    // K > 128 (one workgroup per CU, one LDS image) keeps part of its operands in AGPRs; the copies the compiler makes for an inline-asm MFMA sit right in
-                    // front of it, and the hazard recogniser cannot see into the asm (measured: ~1 % wrong sums in the W-step).
-                    // The builtin is an instruction the compiler knows: it places the wait states itself.
-                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
-                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
+            // Position e = 2 s + T of the chain: its MFMA (if COND), then what rides along with it -- the operand ring, the staging of the
+            // next chunk.  A macro, not a lambda: with the body behind a by-reference closure the register allocator spilled (K = 240, 256).
+            // K % 64 != 0: the chain ends in a branch (p1_trim) whose arms may keep s0 / s1 in different registers, and the copies
+            // at the join would sit next to asm MFMAs the compiler cannot see into (tools/asm_audit.py).
+            // K > 128 (one workgroup per CU, one LDS image) keeps part of its operands in AGPRs; the copies the compiler makes for an inline-asm MFMA sit right in
+            // front of it, and the hazard recogniser cannot see into the asm (measured: ~1 % wrong sums in the W-step).
+            // The builtin is an instruction the compiler knows: it places the wait states itself.
+#define NMF_P1_POSITION(e, COND)                                                                                                                     \
+                {                                                                                                                    \
+                    const int s = (e) >> 1;                                                                                          \
+                    if (COND) {                                                                                                      \
+                    if (KT > 8 || RR > 0) {                                                                                          \
+                        if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
+                        else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
+                        else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
+                        else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);                                                      \
+                    }                                                                                                                \
+                    else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));       \
+                    else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));       \
+                    else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));  \
+                    else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));  \
+                    }                                                                                                                \
+                    if (e + D < E1) ar[e % D] = a1_ld(e + D);                                                                        \
+                    if (!LAST && e >= G && e % G == 0 && e / G - 1 < NLOAD) {                                                        \
+                        const int l = e / G - 1;                                                                                     \
+                        if (l < NPC) stage_load_one(l); else x_load_one(l - NPC);                                                    \
+                        __builtin_amdgcn_sched_barrier(0);                                                                           \
+                    }                                                                                                                \
                 }
-                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
-                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
-                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
-                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
-                if (e + D < E1) ar[e % D] = a1_ld(e + D);
-                if (!LAST && e >= G && e % G == 0 && e / G - 1 < NLOAD) {
-                    const int l = e / G - 1;
-                    if (l < NPC) stage_load_one(l); else x_load_one(l - NPC);
-                    __builtin_amdgcn_sched_barrier(0);
+            // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
+            // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
+            constexpr int ET = RR > 0 ? E1 - 6 : E1;
+#pragma unroll
+            for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
+            if (RR > 0) {
+                if (n1_run == N1) {
+#pragma unroll
+                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)
+                } else {
+#pragma unroll
+                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, ((e) >> 1) < n1_run)
                 }
             }
+#undef NMF_P1_POSITION
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             // ---- first operands of product 2, then the quotient in one VALU block

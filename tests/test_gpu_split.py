@@ -55,8 +55,8 @@ def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
         assert np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all()
 
 
-@pytest.mark.parametrize("K", [48, 96, 100, 160, 192, 200, 224])
-@pytest.mark.parametrize("M,N,split_kernel", [(512, 768, 1), (1024, 4096, -1)])
+@pytest.mark.parametrize("M,N,K,split_kernel", [(512, 768, K, 1) for K in (48, 96, 100, 160, 192, 200, 224)] +
+                         [(1024, 4096, K, -1) for K in (48, 100, 192)] + [(1024, 2048, K, -1) for K in (96, 160, 200, 224)])
 def test_k_between_the_powers_of_two_200_iterations_vs_oracle(ng, oracle, M, N, K, split_kernel):
     """The K values of round-3 VERDICT item 1 (padded to 128 / 256 until round 3; now computed on the next multiple of 16 in factors
     padded to 32 like the reference's, cuda/matrix.cuh:7): 200 iterations on one small shape through the split kernel and one
@@ -231,6 +231,45 @@ def test_batched_restarts_with_the_batch_sized_split_match_the_oracle_per_restar
         worst = max(worst, _relF(oracle, Wm[i].mat, wr), _relF(oracle, Hm[i].mat, hr))
     print(f"batched restarts {M}x{N}x{K} x{R}: splits lone {s1} -> batch {sb}; worst relF vs oracle {worst:.2e}")
     assert worst < 2e-5 and best == int(np.argmin(kls))
+
+
+@pytest.mark.parametrize("M,N,K,R,thresh,kw", [(2048, 4096, 256, 5, 0.0, {}), (1024, 2048, 320, 4, 0.0, {}), (4096, 1500, 100, 3, 0.0, {"split_kernel": -1}),
+                                               (2048, 1024, 96, 6, 2e-3, {"split_kernel": -1})])
+def test_batched_restarts_on_the_64_column_kernel_match_the_oracle_per_restart(ng, oracle, M, N, K, R, thresh, kw):
+    """Round-3 VERDICT next 5 (paper section 3.2): shapes the split kernel does not take -- K > 256, or above its crossover -- but
+    whose lone launch does not fill the chip run all restarts in every launch of the 64-column kernel too (blockIdx.y = restart:
+    fused_step_kernel_k16, col_sums / apply_partials / apply_w_colsum with a pair dimension, per-pair convergence flags),
+    instead of two stream lanes.  Every restart is held to the oracle's sequential update_div of that pair, with and without a
+    convergence threshold (a converged pair must stay frozen while the others iterate on), and the stream-lane path -- the same
+    arithmetic with a lone pair's splits -- must agree with it to summation order."""
+    X, _, _ = oracle.gen_problem(M, N, K, seed=5)
+    rng = np.random.default_rng(23)
+    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    sb = ng.Solver(M, N, K, batch=R, **kw)
+    assert sb.describe().startswith("fused_step_kernel_k16") and not sb.uses_split_kernel
+    sb.close()
+    Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    ng.record_kernels(True)
+    try:
+        best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=50, converge_thresh=thresh, iter_check=10, **kw)
+    finally:
+        ng.record_kernels(False)
+    Wl, Hl = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    best_l, kls_l = ng.update_div_restarts(Wl, Hl, ng.Matrix(X), max_iter=50, converge_thresh=thresh, iter_check=10, restart_lanes=2, **kw)
+    worst = 0.0
+    stopped = set()
+    for i in range(R):
+        wr, hr, it, _ = oracle.update_div(Ws[i], Hs[i], X, thresh, 50, 10)
+        stopped.add(it)
+        eW, eH = _relF(oracle, Wm[i].mat, wr), _relF(oracle, Hm[i].mat, hr)
+        worst = max(worst, eW, eH)
+        assert eW < 2e-5 and eH < 2e-5, (i, eW, eH)
+        assert _relF(oracle, Wl[i].mat, Wm[i].mat) < 2e-5 and _relF(oracle, Hl[i].mat, Hm[i].mat) < 2e-5, i
+        klr = oracle.kl_div(oracle.clamp(X), oracle.clamp(oracle.sgemm("nn", wr, hr)))
+        assert abs(kls[i] - klr) <= 1e-4 * abs(klr) and abs(kls_l[i] - kls[i]) <= 1e-4 * abs(klr)
+    assert best == int(np.argmin(kls))
+    print(f"batched restarts on the 64-column kernel {M}x{N}x{K} x{R}, thresh {thresh}: worst relF vs oracle {worst:.2e}; oracle stopped after {sorted(stopped)} iterations")
 
 
 @pytest.mark.parametrize("split_kernel", [1, -1])

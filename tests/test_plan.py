@@ -46,12 +46,16 @@ def test_dispatch_table(ng, shape, batch, want):
 
 
 def test_plans_that_are_refused(ng):
-    with pytest.raises(ng.NmfError) as e:          # a batch needs the split kernel: K <= 256
-        ng.plan_describe(1024, 1024, 300, 4)
+    with pytest.raises(ng.NmfError) as e:          # a batch needs the split kernel or the 64-column kernel: not the wave-pair kernel (K > 512)
+        ng.plan_describe(1024, 1024, 700, 4)
     assert e.value.status == 7
-    with pytest.raises(ng.NmfError) as e:          # nor a shape that fills the chip by itself
-        ng.plan_describe(4096, 65536, 256, 2)
+    with pytest.raises(ng.NmfError) as e:          # nor the 32-column kernel
+        ng.plan_describe(4096, 65536, 30, 2, split_kernel=-1)
     assert e.value.status == 7
+    # round 4: a batch on the 64-column kernel (blockIdx.y = pair); the splits shrink with the batch
+    assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=20> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(8,1)"
+    assert ng.plan_describe(4096, 4096, 256, 1) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(8,8)"
+    assert ng.plan_describe(4096, 4096, 256, 8) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(1,1)"
     with pytest.raises(ng.NmfError):
         ng.plan_describe(0, 10, 4)
     # explicit overrides reach the plan
