@@ -87,17 +87,23 @@ typedef const __attribute__((address_space(1))) char *global_bytes;
 #define NMF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // k index of product-1 step s in lane group kq = l >> 4: whole blocks of 64 first, 64 (s >> 4) + 16 kq + (s & 15) -- per-lane
 // contiguous runs of 16 (16-B loads of the owned factor) and, with 33-float LDS rows, 32 distinct banks per half-wave -- then,
-// where K is not a multiple of 64, one remainder block of R = (K % 64) / 4 = 4, 8 or 12 steps INTERLEAVED over the lane groups:
-// 64 (K / 64) + 4 s' + kq.  The two lane groups of a half-wave then sit one LDS row apart (2-way conflicts on those ds_reads:
-// 4 LDS cycles instead of 2 next to a 32-cycle MFMA), and in exchange the last steps cover the TOP k indices: where the caller's
-// K is not a multiple of 16 the last one to three steps hold zero padding only and are skipped at run time (FusedArgs::p1_trim),
-// so product 1 runs at a granularity of 4 in K while product 2 (16 x 16 output tiles) keeps 16.
+// where K is not a multiple of 64, one remainder block of R = (K % 64) / 4 = 4, 8 or 12 steps, in one of two arrangements:
+//   IL = false: runs of R per lane group, 64 (K / 64) + R pi(kq) + s', pi = (0, 2, 1, 3): the two lane groups of a half-wave sit
+//               2 R apart (conflict-free LDS reads at R = 8, 2-way on half of the lanes at R = 4, 12), 16-B loads of the owned factor;
+//   IL = true:  interleaved over the lane groups, 64 (K / 64) + 4 s' + kq: 2-way conflicts on those ds_reads (4 LDS cycles instead of
+//               2 next to a 32-cycle MFMA), and in exchange the last steps cover the TOP k indices -- where the caller's K is not a
+//               multiple of 16 the last one to three steps hold zero padding only and can be skipped at run time
+//               (FusedArgs::p1_trim): product 1 then runs at a granularity of 4 in K while product 2 (16 x 16 tiles) keeps 16.
 // k16_kconst: the part of that index that does not depend on the lane ...
-template <int KT> __host__ __device__ constexpr int k16_kconst(int s) {
-    return s < 16 * (KT / 4) ? 64 * (s >> 4) + (s & 15) : 64 * (KT / 4) + 4 * (s - 16 * (KT / 4));
+template <int KT, bool IL> __host__ __device__ constexpr int k16_kconst(int s) {
+    return s < 16 * (KT / 4) ? 64 * (s >> 4) + (s & 15) : 64 * (KT / 4) + (IL ? 4 : 1) * (s - 16 * (KT / 4));
 }
-// ... and whether the step lies in the remainder block (lane part kq instead of 16 kq)
+// ... whether the step lies in the remainder block ...
 template <int KT> __host__ __device__ constexpr bool k16_in_rem(int s) { return s >= 16 * (KT / 4); }
+// ... and the lane part of a remainder step (whole blocks: 16 kq)
+template <int KT, bool IL> __device__ __forceinline__ int k16_rem_lane(int kq) {
+    return IL ? kq : ((16 * KT) % 64) / 4 * (((kq & 1) << 1) | (kq >> 1));
+}
 
 // DIV = 0: correctly rounded IEEE division (hipcc's expansion of `/`, 11 VALU);
 // DIV = 1: reciprocal refined to <= 1 ulp (rcp, 2 fma, mul, 2 fma; no scaling: y >= EPS is normal here)

@@ -44,7 +44,13 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
-    const int n1_run = N1 - (RR > 0 ? a.p1_trim : 0);
+    // Two workgroups per CU (K <= 256): the remainder block is interleaved and its last steps can be switched off at run time.  With one
+    // wave per SIMD (K > 256; the split kernel) the branch and the compiler-placed MFMAs it requires cost more than the skipped
+    // MFMAs save (measured on the split kernel: -3 % with three steps skipped, -9 .. -12 % with none), so those keep the run map.
+    constexpr bool TRIMMABLE = RR > 0 && KT <= 16;
+    constexpr bool IL = TRIMMABLE;
+    const int n1_run = N1 - (TRIMMABLE ? a.p1_trim : 0);
+    const int rl = k16_rem_lane<KT, IL>(kq);   // lane part of the k index in the remainder block
     const int P = WSTEP ? a.Np : a.Mp;
     const int Q = WSTEP ? a.Mp : a.Np;
     const int nsplit = a.nsplit;
@@ -75,14 +81,22 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
                 ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
             }
-        if (RR > 0) {   // the remainder block is interleaved over the lane groups: one dword per step
-            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + kq) + (size_t)(q0 + j) * ldu;
+        if (RR > 0) {   // the remainder block: one dword per step (interleaved) or a run of RR (a multiple of 4: 16-B loads)
+            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + rl) + (size_t)(q0 + j) * ldu;
+            if (IL) {
 #pragma unroll
-            for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
+                for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
+            } else {
+#pragma unroll
+                for (int e4 = 0; e4 < RR / 4; ++e4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(colr + 4 * e4);
+                    ub[NF + 4 * e4] = v[0]; ub[NF + 4 * e4 + 1] = v[1]; ub[NF + 4 * e4 + 2] = v[2]; ub[NF + 4 * e4 + 3] = v[3];
+                }
+            }
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? kq : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT, IL>(s) + (k16_in_rem<KT>(s) ? rl : 16 * kq)) * ldu];
     }
 
     f32x4 acc[NT];
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         float *xt_w = WSTEP ? xt + (lane >> 2) * 20 + 4 * (lane & 3) : xt + (lane >> 3) * kXtLd + 4 * (lane & 7);
         const float *xt_r = WSTEP ? xt + 4 * kq * 20 + j : xt + j * kXtLd + 4 * kq;
         const int p1_off = 16 * kq * kLdv + j;     // + k16_kconst(s) * kLdv + 16 T
-        const int p1r_off = kq * kLdv + j;         // the same for the steps of the remainder block
+        const int p1r_off = rl * kLdv + j;         // the same for the steps of the remainder block
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
         f32x4 st[NST];
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT>(e >> 1) * kLdv + 16 * (e & 1)); };
+            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
             // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
             float vs_in = 0.f;
             if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 {                                                                                                                    \
                     const int s = (e) >> 1;                                                                                          \
                     if (COND) {                                                                                                      \
-                    if (KT > 24 || RR > 0) {                                                                                         \
+                    if (KT > 24 || TRIMMABLE) {                                                                                         \
                         if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
                         else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
                         else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
@@ -240,10 +254,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 }
             // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
             // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
-            constexpr int ET = RR > 0 ? E1 - 6 : E1;
+            constexpr int ET = TRIMMABLE ? E1 - 6 : E1;
 #pragma unroll
             for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
-            if (RR > 0) {
+            if (TRIMMABLE) {
                 if (n1_run == N1) {
 #pragma unroll
                     for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)

@@ -331,9 +331,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         s->Kc = s->Kp;
     }
     s->path = path;
-    // product 1 of the 16-column kernels steps through K four at a time: the steps beyond pad4(K) hold zero padding only
+    // product 1 of the 64-column kernel steps through K four at a time: the steps beyond pad4(K) hold zero padding only (K <= 256:
+    // two workgroups per CU; one wave per SIMD does not earn the branch back, nmf_split16_impl.h)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && s->Kc >= 32 && s->Kc <= 512 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc <= 256 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
     if (s->p1_trim > 3) s->p1_trim = 3;
     if (getenv("NMF_NO_P1_TRIM")) s->p1_trim = 0;
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
@@ -724,7 +725,7 @@ static SplitArgs split_args(nmf_solver *s) {
     SplitArgs a;
     a.W = s->W; a.H = s->H; a.X = s->X;
     a.U_out = nullptr; a.partials = s->partials; a.vpart = s->vpart;
-    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.p1_trim = s->p1_trim; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
+    a.Mp = s->Mp; a.Np = s->Np; a.Kp = s->Kp; a.Kc = s->Kc; a.nsplit = 1; a.batch = s->batch; a.force_partial = 0;
     a.nw_h = s->nw_h; a.nw_w = s->nw_w;
     // 64 < K <= 128: two workgroups per CU pay once a launch hands out more than one workgroup per CU (a batch of restarts)
     const bool mid_k = s->Kp > 64 && s->Kp <= 128;

@@ -34,7 +34,7 @@ struct FusedArgs {
     int Mp, Np, Kp;
     int Kc = 0;               // 16-column kernel: the K its MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (rows / columns Kc .. Kp - 1 of
                               //    the factors are zero padding); 0 = Kp.  The other families compute on Kp.
-    int p1_trim = 0;          // 16-column kernel, Kc % 64 != 0: the last p1_trim (0 .. 3) steps of product 1 cover zero padding only (the
+    int p1_trim = 0;          // 64-column kernel, Kc <= 256, Kc % 64 != 0: the last p1_trim (0 .. 3) steps of product 1 cover zero padding only (the
                               //    caller's K <= Kc - 4 p1_trim) and are skipped: product 1 at a granularity of 4 in K (nmf_device.h)
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
@@ -89,7 +89,6 @@ struct SplitArgs {
     float *vpart;             // nsplit  > 1
     int Mp, Np, Kp;
     int Kc = 0;               // the K the MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (split_compute_k); 0 = Kp
-    int p1_trim = 0;          // as FusedArgs::p1_trim
     int Mv, Nv;               // M, N rounded up to 32: column groups beyond them hold only zero padding and get no workgroup
     int nsplit;
     int nw_h, nw_w;           // waves per workgroup (4 or 8) of the H- and the W-step: reduction length % (32 nw) == 0; 8 needs Kp == 64

@@ -55,8 +55,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
     constexpr int RR = (K % 64) / 4;    // product-1 steps in the remainder block (0, 4, 8, 12): step s' covers k = 64 (K / 64) + 4 s' + kq
     constexpr int D = kRing < 2 * N1 ? kRing : 2 * N1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
-    // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
-    const int n1_run = N1 - (RR > 0 ? a.p1_trim : 0);
+    // One wave per SIMD has nobody to hide a branch in the MFMA chain behind: the 64-column kernel's run-time trimming of product 1
+    // (FusedArgs::p1_trim; it needs compiler-placed MFMAs and a branch at the end of the chain) measured -3 % here with three steps
+    // skipped and -9 .. -12 % with none.  The remainder block keeps the run map (IL = false: conflict-free at K % 64 = 32) and the
+    // chain stays straight-line inline asm.
+    constexpr bool TRIMMABLE = false;
+    constexpr bool IL = false;
+    const int n1_run = N1;
+    const int rl = k16_rem_lane<KT, IL>(kq);   // lane part of the k index in the remainder block
     const int b = blockIdx.y;
     if (a.active != nullptr && a.active[b] == 0) return;
     const int P = WSTEP ? a.Np : a.Mp;   // a multiple of 32 NW: every superchunk is whole
@@ -95,14 +101,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
                 ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
             }
-        if (RR > 0) {   // the remainder block is interleaved over the lane groups: one dword per step
-            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + kq) + (size_t)(q0 + j) * ldu;
+        if (RR > 0) {   // the remainder block: a run of RR (a multiple of 4: 16-B aligned) at 64 (K / 64) + RR pi(kq)
+            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + rl) + (size_t)(q0 + j) * ldu;
 #pragma unroll
-            for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
+            for (int e4 = 0; e4 < RR / 4; ++e4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(colr + 4 * e4);
+                ub[NF + 4 * e4] = v[0]; ub[NF + 4 * e4 + 1] = v[1]; ub[NF + 4 * e4 + 2] = v[2]; ub[NF + 4 * e4 + 3] = v[3];
+            }
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT>(s) + (k16_in_rem<KT>(s) ? kq : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT, IL>(s) + (k16_in_rem<KT>(s) ? rl : 16 * kq)) * ldu];
     }
 
     // The values this wave will update in the epilogue (tiles t = wave, wave + NW, ...: U(16 t + 4 kq + r, q0 + j)), fetched
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         const int xw_off = WSTEP ? (lane >> 2) * 20 + 4 * (lane & 3) : (lane >> 3) * kXtLd + 4 * (lane & 7);
         const int xr_off = WSTEP ? 4 * kq * 20 + j : j * kXtLd + 4 * kq;
         const int p1_off = 16 * kq * kLdv + j;     // + k16_kconst(s) * kLdv + 16 T
-        const int p1r_off = kq * kLdv + j;         // the same for the steps of the remainder block
+        const int p1r_off = rl * kLdv + j;         // the same for the steps of the remainder block
         const int p2_off = j * kLdv + 4 * kq;      // + 16 t * kLdv + 16 T + r
 
         f32x4 st[NPC];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT>(e >> 1) * kLdv + 16 * (e & 1)); };
+            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
             constexpr int E1 = 2 * N1;
             float ar[D];
 #pragma unroll
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 {                                                                                                                    \
                     const int s = (e) >> 1;                                                                                          \
                     if (COND) {                                                                                                      \
-                    if (KT > 8 || RR > 0) {                                                                                          \
+                    if (KT > 8 || TRIMMABLE) {                                                                                          \
                         if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
                         else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
                         else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
@@ -303,10 +312,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 }
             // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
             // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
-            constexpr int ET = RR > 0 ? E1 - 6 : E1;
+            constexpr int ET = TRIMMABLE ? E1 - 6 : E1;
 #pragma unroll
             for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
-            if (RR > 0) {
+            if (TRIMMABLE) {
                 if (n1_run == N1) {
 #pragma unroll
                     for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)

@@ -56,4 +56,14 @@ def ng():
     return m
 
 
+@pytest.fixture(scope="session")
+def cfg3_problem(oracle):
+    """BASELINE config 3's seed-0 inputs (4096 x 65536 x 256: the generator needs ~8 s for the 268 M entries of X), drawn once
+    per session and shared by the cfg3 tests.  Read-only: a test that changes them must copy."""
+    X, W, H = oracle.gen_problem(4096, 65536, 256, seed=0)
+    for a in (X, W, H):
+        a.setflags(write=False)
+    return X, W, H
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")

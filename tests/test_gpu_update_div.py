@@ -245,21 +245,14 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     s.close()
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 2, 25)
     print("cfg3 K_par=2 relF =", _cmp(oracle, Wg, Hg, Wr, Hr, 1e-5, wh=False))
-    # K_par = 10 ("K_par iterations small enough for the CPU to finish", ~0.55 TFLOP each): the oracle's fast
-    # arrangement (same arithmetic around its fastest SGEMM kernel) first has to equal the pinned loop at THIS shape
+    # the oracle's fast arrangement (same arithmetic around its fastest SGEMM kernel), which the 200-iteration test below iterates,
+    # first has to equal the pinned loop at THIS shape
     W1r, H1r, _, _ = oracle.update_div(W, H, X, 0.0, 1, 25)
     W1f, H1f = oracle.update_div_fast(W, H, X, 1)
     assert oracle.relF(W1f, W1r) < 5e-6 and oracle.relF(H1f, H1r) < 5e-6
-    W10, H10 = oracle.update_div_fast(W, H, X, 10)
-    s = ng.Solver(M, N, K)
-    s.upload(W, H, X)
-    s.iterate(10)
-    Wg, Hg = s.download()
-    s.close()
-    print("cfg3 K_par=10 relF =", _cmp(oracle, Wg, Hg, W10, H10, 2e-5, wh=False))
 
 
-def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
+def test_cfg3_200_iterations_against_the_oracle(ng, oracle, cfg3_problem):
     """north_star's headline parity gate: "W/H matching reference within 1e-4 rel after 200 iterations" at
     (M, N, R) = (4096, 65536, 256), BASELINE config 3 -- the full 200 iterations on both sides, same seed-0 inputs
     (cuda/nmf.cu:10 MAX_ITER; test_output.sh:5-18 is the reference's own 200-iteration comparison).  The CPU side is the
@@ -280,7 +273,7 @@ def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
     the GPU's own sensitivity to summation order (the K-relabelled twin of tests/test_oracle_golden.py moves it by 2e-6)."""
     import time
     M, N, K = 4096, 65536, 256
-    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    X, W, H = cfg3_problem
     blk = slice(N // 2, N // 2 + 2048)
     rng = np.random.default_rng(1)
     pm, pn = rng.permutation(M), rng.permutation(N)
@@ -299,18 +292,20 @@ def test_cfg3_200_iterations_against_the_oracle(ng, oracle):
         cpu_s += time.time() - t0
         eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
         eWH = oracle.relF(Wg @ Hg[:, blk], Wr @ Hr[:, blk])
-        Wp, Hp = sp.download()
-        gW, gH = oracle.relF(Wp, Wg[pm]), oracle.relF(Hp, Hg[:, pn])
+        gW = gH = float("nan")
+        if stage == 3:     # the twin's distance at the end (it grows monotonically: 3.7e-6 -> 9.6e-6 over the four stages in round 3)
+            Wp, Hp = sp.download()
+            gW, gH = oracle.relF(Wp, Wg[pm]), oracle.relF(Hp, Hg[:, pn])
         scale = float(np.vdot(Wg.astype(np.float64), Wr.astype(np.float64)) / np.vdot(Wr.astype(np.float64), Wr.astype(np.float64))) - 1.0
         rows.append((50 * (stage + 1), eW, eH, eWH, gW, gH, scale))
     kl_gpu, _ = s.check()
     s.close(); sp.close()
     for it, eW, eH, eWH, gW, gH, scale in rows:
         print(f"cfg3 after {it:3d} iterations: GPU vs oracle relF(W) = {eW:.2e}, relF(H) = {eH:.2e}, relF(W*H block) = {eWH:.2e}, "
-              f"scale of W {scale:+.1e}; GPU vs its row/column-permuted twin {gW:.2e}, {gH:.2e}")
+              f"scale of W {scale:+.1e}" + (f"; GPU vs its row/column-permuted twin {gW:.2e}, {gH:.2e}" if gW == gW else ""))
     print(f"cfg3 x 200: {cpu_s:.0f} s of CPU; KL(gpu) = {kl_gpu:.6e}")
     assert all(r[1] < 1e-4 and r[2] < 1e-4 and r[3] < 1e-4 for r in rows)       # north_star's tolerance, fp32 relative (Frobenius), at every stage
-    assert all(r[4] < 5e-5 and r[5] < 5e-5 for r in rows)                      # the GPU's own sensitivity to the order of its sums
+    assert rows[-1][4] < 5e-5 and rows[-1][5] < 5e-5                           # the GPU's own sensitivity to the order of its sums
     assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
 
 
@@ -364,13 +359,13 @@ def test_small_shapes_200_iterations_against_fp64(ng, oracle, M, N, K):
     assert eW < 1e-4 and eH < 1e-4 and eWH < 1e-4
 
 
-def test_cfg3_against_an_fp64_evaluation(ng, oracle):
+def test_cfg3_against_an_fp64_evaluation(ng, oracle, cfg3_problem):
     """BASELINE config 3 at full size against float64 numpy directly (no oracle in between), 10 iterations from the seed-0
     inputs: closes the chain GPU ~ oracle (200 iterations, previous test) and oracle ~ fp64 (tests/test_oracle_ops.py) at the
     headline shape itself.  ~1 TFLOP of fp64 BLAS per iteration on the host."""
     import time
     M, N, K, iters = 4096, 65536, 256, 10
-    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    X, W, H = cfg3_problem
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
     s.iterate(iters)
