@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                 }
             }
 #undef NMF_P1_POSITION
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+            // An MFMA's result needs 12 wait states (8 passes + 4) before anything but an accumulating MFMA touches it, and the compiler
+            // pads nothing behind an asm MFMA.  GEMM / CHECK read it at once: twelve nops.  The half-step first issues the eight LDS
+            // reads of product 2's operand ring, which count: six nops behind them (tools/asm_audit.py checks every kernel's code).
+            if (GEMM || CHECK) asm volatile("s_nop 11" : "+v"(s0), "+v"(s1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             if (GEMM) {   // lane holds S(p0 + 16 T + 4 kq + r, q0 + j): two 16-B stores per chunk, 64 B contiguous per column and half
                 if (active) {
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
 #pragma unroll
             for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
             float z[8];
+            asm volatile("s_nop 5" : "+v"(s0), "+v"(s1));   // D = 8 ds_reads + 6: the wait states of product 1's last MFMAs
             __builtin_amdgcn_sched_barrier(0);
             quotient8<DIV>(xr, s0, s1, z, x_in_range);
             if (WSTEP && PARTIAL) vs_acc += vs_in;

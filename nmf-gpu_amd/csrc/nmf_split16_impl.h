@@ -325,7 +325,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
                 }
             }
 #undef NMF_P1_POSITION
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             // ---- first operands of product 2, then the quotient in one VALU block
             const lds_float *b2 = (const lds_float *)vb + p2_off;
@@ -334,6 +333,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
 #pragma unroll
             for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
             float z[8];
+            // An MFMA's result needs 12 wait states (8 passes + 4) before anything but an accumulating MFMA touches it, and the compiler
+            // pads nothing behind an asm MFMA: the D = 8 LDS reads above count, six nops make up the rest (tools/asm_audit.py checks).
+            static_assert(D == 8, "the wait states behind product 1 count on eight ds_reads");
+            asm volatile("s_nop 5" : "+v"(s0), "+v"(s1));
             __builtin_amdgcn_sched_barrier(0);
             quotient8<DIV>(xr, s0, s1, z, x_in_range);
             __builtin_amdgcn_sched_barrier(0);
