@@ -18,7 +18,7 @@ def pytest_configure(config):
     pkg = os.path.join(ROOT, "nmf-gpu_amd")
     if not (os.path.exists(os.path.join(pkg, "libnmf_mi355x.so")) and os.path.exists(os.path.join(pkg, "nmf"))):
         import subprocess
-        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(pkg, "csrc"), "all"], check=True)
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(pkg, "csrc"), "all"], check=True)
 
 
 def _has_gpu() -> bool:

@@ -41,9 +41,11 @@ def test_refcompat_reproduces_reference_golden_outputs(oracle):
     """refcompat = the intended loop minus row_divide (invalid launch, cuda/matrix.cu:215-217) with
     sum_cols returning 14 of 128 partials (cuda/matrix.cu:676-683), 200 iterations.
 
-    Tolerance: the gold run is a winner-take-all dynamic that amplifies fp32 summation-order noise:
-    the same model evaluated in fp64, or in fp32 with a different GEMM summation order, lands
-    4e-5..1.5e-4 (W) / 2e-4..1.1e-3 (H) from the gold (measured), so those are the bounds.
+    Tolerance, plainly: BASELINE.md's gate for this configuration is 1e-4 on both factors, and it is NOT met on H -- the oracle
+    lands 6.8e-5 (W) and 4.3e-4 (H) from the reference's files, asserted below at 1e-4 / 6e-4.  Why it cannot be met: the gold run
+    is a winner-take-all dynamic (17 of 128 components survive) that amplifies fp32 summation-order noise, and the reference's
+    sums ran in closed-source cuBLAS whose order is unknowable; the same model evaluated in fp32 with the K components merely
+    relabelled lands 8e-5..1.8e-4 (H) from the unpermuted run and 2.7e-4..4.3e-4 from the gold (next test: measured, not allowed).
     The discrete structure must match exactly: zero counts and the set of surviving components."""
     X, W, H = oracle.gen_problem(4096, 350, 128, seed=0)
     w, h, it, _ = oracle.update_div(W, H, X, 0.0, 200, 25, oracle.MODE_REFCOMPAT)
@@ -52,7 +54,7 @@ def test_refcompat_reproduces_reference_golden_outputs(oracle):
     assert it == 200 and Wg.shape == (4096, 128) and Hg.shape == (128, 350)
     eW, eH = oracle.relF(w, Wg), oracle.relF(h, Hg)
     print("refcompat vs gold: relF(W)=%.3g relF(H)=%.3g" % (eW, eH))
-    assert eW < 1e-4 and eH < 6e-4       # measured 6.8e-5 / 4.3e-4; why not smaller: test_gold_distance_is_summation_order_noise
+    assert eW < 1e-4 and eH < 6e-4       # measured 6.8e-5 / 4.3e-4: H misses BASELINE.md's 1e-4; why: test_gold_distance_is_summation_order_noise
     assert abs(int((w == 0).sum()) - 457204) <= 5 and int((h == 0).sum()) == 38850
     surv = np.flatnonzero(h.sum(axis=1) > 0)
     assert list(surv) == [1, 22, 30, 34, 43, 45, 57, 70, 88, 89, 93, 96, 110, 113, 118, 121, 126]
