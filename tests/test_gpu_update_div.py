@@ -360,11 +360,11 @@ def test_small_shapes_200_iterations_against_fp64(ng, oracle, M, N, K):
 
 
 def test_cfg3_against_an_fp64_evaluation(ng, oracle, cfg3_problem):
-    """BASELINE config 3 at full size against float64 numpy directly (no oracle in between), 10 iterations from the seed-0
+    """BASELINE config 3 at full size against float64 numpy directly (no oracle in between), 6 iterations from the seed-0
     inputs: closes the chain GPU ~ oracle (200 iterations, previous test) and oracle ~ fp64 (tests/test_oracle_ops.py) at the
     headline shape itself.  ~1 TFLOP of fp64 BLAS per iteration on the host."""
     import time
-    M, N, K, iters = 4096, 65536, 256, 10
+    M, N, K, iters = 4096, 65536, 256, 6
     X, W, H = cfg3_problem
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
@@ -407,14 +407,14 @@ def test_cfg3_200_iterations_kl_monotone(ng):
 
 def test_cfg5_tall_skinny_r512(ng, oracle):
     """BASELINE config 5 (M=8192, N=131072, R=512; K > 256 takes the 16x16x4 kernel with NB = 8).  The shard one
-    of 8 GPUs owns (N/8 = 16384 columns) is checked against the oracle after K_par = 1 iteration; the unsharded
-    problem (X = 4 GiB) is checked through the update's conservation invariants and KL monotonicity."""
+    of 8 GPUs owns (N/8 = 16384 columns) is checked against the oracle after K_par = 1 and 5 iterations and through 200 iterations of
+    KL monotonicity; the unsharded problem (X = 4 GiB) has a test of its own below."""
     M, N, K = 8192, 131072, 512
     rng = np.random.default_rng(5)
-    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
     ns = N // 8
+    X = np.asfortranarray(rng.random((M, ns), dtype=np.float32))      # the shard's columns only
+    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
+    H = np.asfortranarray(rng.random((K, ns), dtype=np.float32))
     s = ng.Solver(M, ns, K)
     s.upload(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]))
     s.iterate(1)
@@ -440,20 +440,7 @@ def test_cfg5_tall_skinny_r512(ng, oracle):
     s.close()
     kl = np.asarray(r["kl"])
     assert r["iterations"] == 200 and len(kl) == 9 and np.all(np.diff(kl) < 0) and np.isfinite(kl).all()
-    s = ng.Solver(M, N, K)
-    s.upload(W, H, X)
-    kl0, _ = s.check()
-    s.update_h()
-    W1, H1 = s.download()
-    assert np.allclose(W1.astype(np.float64).sum(axis=0) @ H1.astype(np.float64), X.sum(axis=0, dtype=np.float64), rtol=2e-5)
-    s.update_w()
-    W2, H2 = s.download()
-    assert np.allclose(W2.astype(np.float64) @ H2.astype(np.float64).sum(axis=1), X.sum(axis=1, dtype=np.float64), rtol=2e-5)
-    kl1, _ = s.check()
-    s.iterate(2)
-    kl2, _ = s.check()
-    s.close()
-    assert kl0 > kl1 > kl2 > 0
+    # (the unsharded problem, X = 4 GiB: test_cfg5_full_size_against_the_oracle_unsharded_and_as_eight_shards)
 
 
 def test_cli_reference_workflow(ng, oracle, tmp_path):
