@@ -57,7 +57,7 @@ def test_matrix_multiply_identity_asymmetric(ng):
     assert np.array_equal(c3.from_device().mat, B)
 
 
-@pytest.mark.parametrize("k", [64, 128, 256, 384, 512])
+@pytest.mark.parametrize("k", [64, 96, 128, 160, 224, 256, 288, 384, 512])
 def test_matrix_multiply_wh_shape_exact_lane_map(ng, k):
     """The W*H-shaped product (tall A, K <= 512) runs on the 16-column kernel's product 1 with B held in registers:
     with B a 0/1 selection matrix every output column must be an exact copy of one column of A."""

@@ -1,8 +1,8 @@
-"""Soak: 10 000 iterations at cfg3 with a KL check every 1000 (monotone, finite); ~40 s."""
+"""Soak: 10 000 iterations at cfg3 (or M N K from the command line) with a KL check every 1000 (monotone, finite); ~40 s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nmf_gpu_amd as ng
-M, N, K = 4096, 65536, 256
+M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 65536, 256)
 rng = np.random.default_rng(0)
 s = ng.Solver(M, N, K)
 s.upload(np.asfortranarray(rng.random((M, K), dtype=np.float32)), np.asfortranarray(rng.random((K, N), dtype=np.float32)), np.asfortranarray(rng.random((M, N), dtype=np.float32)))

@@ -4,7 +4,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, nmf_gpu_amd as ng
 rng = np.random.default_rng(0)
-for (M, N, K) in ((1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)):
+shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1024, 4096, 64), (4096, 350, 128), (512, 3445, 30)]
+for (M, N, K) in shapes:
     X = np.asfortranarray(rng.random((M, N), dtype=np.float32)); W = np.asfortranarray(rng.random((M, K), dtype=np.float32)); H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
     finals = []
     for rep in range(2):
