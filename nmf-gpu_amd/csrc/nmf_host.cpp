@@ -271,8 +271,12 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     if (o.split_kernel > 0) return true;
     // measured crossover (tools/crossover.py, iteration time of both families over M x N from 2^22 to 2^26 elements): the split
     // kernel is 5-26 % ahead up to 2^23 elements at K = 128 and 2^23-2^24 at K = 64 (a tie at 2^24), 3-14 % behind beyond; at
-    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25; at 128 < K <= 256 (one LDS image) 5-58 % ahead up to 2^22
-    const int lg = kp <= 32 ? 26 : (kp <= 64 ? 24 : (kp <= 128 ? 23 : 22));
+    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25; at K = 256 (one LDS image) 5-58 % ahead up to 2^22.
+    // Round 4, the ranks in between (profiles/r04_crossover_mid_k.log): K = 80 .. 112 ahead or level through 2^24 (K = 96: +13 % at
+    // 2^23, +3 % at 2^24, -4 % at 2^25); K = 144 .. 224 ahead through 2^23 (K = 160: +26 / +12 %, then -9 % at 2^24; K = 224: +3 %
+    // at 2^23); K = 256 behind from 2^23 on.
+    const int kc = split_compute_k(K);
+    const int lg = kc <= 32 ? 26 : (kc <= 112 ? 24 : (kc <= 224 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
