@@ -1,6 +1,6 @@
 // nmf_fused32.hip -- the 32-column fused half-step family (v_mfma_f32_32x32x2_f32): v3, the kernel for K <= 32 and
 // NMF_FUSED_VARIANT=3; v1, the first chunk-serial kernel, kept as the 64-bit-addressing fallback and for the
-// ablation probes; their KL check.  The production kernel for K >= 64 is in nmf_fused16.hip.
+// ablation probes; their KL check.  The production kernel for K >= 64 is in nmf_fused16_impl.h.
 //
 // Written for wave64 + the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.  Operand / result maps
 // used everywhere below (lane l: c = l & 31, h = l >> 5):

@@ -58,7 +58,7 @@ extern "C" const char *nmf_status_string(int st) {
         default: return "unknown status";
     }
 }
-extern "C" const char *nmf_version(void) { return "nmf_mi355x 0.3 (gfx950)"; }
+extern "C" const char *nmf_version(void) { return "nmf_mi355x 0.4 (gfx950)"; }
 
 extern "C" int nmf_device_count(void) {
     int n = 0;
@@ -108,7 +108,7 @@ struct nmf_solver {
     int use_graph = 1;
     int nsplit_h = 1, nsplit_w = 1;
     int fast_divide = 0;
-    // split path (nmf_split16.hip): four waves per 16 owned columns, normalisers summed in-stream, `batch` (W, H) pairs per launch
+    // split path (nmf_split16_impl.h): four waves per 16 owned columns, normalisers summed in-stream, `batch` (W, H) pairs per launch
     bool split = false;
     int batch = 1;
     int split_batch = 1;           // restarts in the whole update_div_restarts call this solver serves a share of (>= batch): what pick_split sees
@@ -494,7 +494,8 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
     else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
-    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
+                                                               s->p1_trim == 1 ? " p1_trim=1" : (s->p1_trim == 2 ? " p1_trim=2" : (s->p1_trim == 3 ? " p1_trim=3" : "")));
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     return NMF_OK;
 }

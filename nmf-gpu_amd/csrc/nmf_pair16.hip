@@ -6,7 +6,7 @@
 //   1. each wave forms its half of S = V_chunk * U over its k range (two interleaved MFMA chains),
 //   2. the halves meet in LDS (1 KiB per wave), both waves add them in the same order and take the quotient Z = X ./ max(S, EPS),
 //   3. each wave accumulates Acc[k range] += V_chunk[:, k range]' * Z -- no MFMA is issued twice, no accumulator is shared.
-// Same v_mfma_f32_16x16x4_f32 lane maps as nmf_fused16.hip (lane l: j = l & 15, kq = l >> 4; A = A[row j][k kq],
+// Same v_mfma_f32_16x16x4_f32 lane maps as nmf_fused16_impl.h (lane l: j = l & 15, kq = l >> 4; A = A[row j][k kq],
 // B = B[k kq][col j], result register r = D[4 kq + r][j]); chunks are 16 rows so that the K x 16 LDS image (row stride 17)
 // can be double-buffered: 2 x 68 KiB at K = 1024.  The X tile (16 x 16) is loaded straight into the accumulator layout.
 // CHECK = true: the KL / rel-L1 check for this K range (product 1 + exchange, terms summed by the h = 0 wave of each pair).

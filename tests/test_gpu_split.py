@@ -1,4 +1,4 @@
-"""GPU parity of the split kernel (nmf_split16.hip: the half-step for problems that do not fill the chip, and for B restarts
+"""GPU parity of the split kernel (nmf_split16_impl.h: the half-step for problems that do not fill the chip, and for B restarts
 per launch) against the CPU oracle and against itself, through the C ABI.
 
 Reference semantics: update_h / update_w, cuda/nmf.cu:118-176; set_epsilon's NaN-passing clamp, cuda/matrix.cu:182-188;
