@@ -94,15 +94,16 @@ typedef const __attribute__((address_space(1))) char *global_bytes;
 //               2 next to a 32-cycle MFMA), and in exchange the last steps cover the TOP k indices -- where the caller's K is not a
 //               multiple of 16 the last one to three steps hold zero padding only and can be skipped at run time
 //               (FusedArgs::p1_trim): product 1 then runs at a granularity of 4 in K while product 2 (16 x 16 tiles) keeps 16.
-// k16_kconst: the part of that index that does not depend on the lane ...
-template <int KT, bool IL> __host__ __device__ constexpr int k16_kconst(int s) {
-    return s < 16 * (KT / 4) ? 64 * (s >> 4) + (s & 15) : 64 * (KT / 4) + (IL ? 4 : 1) * (s - 16 * (KT / 4));
+// NF = product-1 steps in the whole blocks that use the run map (a multiple of 16), RR = steps of the remainder block.
+// k16_kconst: the part of the k index that does not depend on the lane ...
+template <int NF, bool IL> __host__ __device__ constexpr int k16_kconst(int s) {
+    return s < NF ? 64 * (s >> 4) + (s & 15) : 4 * NF + (IL ? 4 : 1) * (s - NF);
 }
 // ... whether the step lies in the remainder block ...
-template <int KT> __host__ __device__ constexpr bool k16_in_rem(int s) { return s >= 16 * (KT / 4); }
+template <int NF> __host__ __device__ constexpr bool k16_in_rem(int s) { return s >= NF; }
 // ... and the lane part of a remainder step (whole blocks: 16 kq)
-template <int KT, bool IL> __device__ __forceinline__ int k16_rem_lane(int kq) {
-    return IL ? kq : ((16 * KT) % 64) / 4 * (((kq & 1) << 1) | (kq >> 1));
+template <int RR, bool IL> __device__ __forceinline__ int k16_rem_lane(int kq) {
+    return IL ? kq : RR * (((kq & 1) << 1) | (kq >> 1));
 }
 
 // DIV = 0: correctly rounded IEEE division (hipcc's expansion of `/`, 11 VALU);

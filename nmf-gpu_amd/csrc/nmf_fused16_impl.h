@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr int VBUF = KS * kLdv;
     constexpr int N1 = 4 * KT;       // product-1 steps per 16-row tile
     constexpr int NT = KT;           // 16 x 16 accumulator tiles
-    constexpr int NF = 16 * (KT / 4);   // product-1 steps in whole 64-blocks of k
-    constexpr int RR = (K % 64) / 4;    // product-1 steps in the remainder block (0, 4, 8, 12): step s' covers k = 64 (K / 64) + 4 s' + kq
+    // Treating the last WHOLE block of 64 as a trimmable remainder too (so that K = 50 or 120 skip their zero steps) was measured and
+    // dropped: K = 50 gained 5 %, but K = 64 itself lost 2.5 % and K = 192 1 % (every product-1 LDS read of that block 2-way conflicted,
+    // compiler-placed MFMAs, the branch), and powers of two are the common case (profiles/r04_last_block_interleave.log).
+    constexpr int NF = 16 * (KT / 4);   // product-1 steps in the whole 64-blocks of k (run map)
+    constexpr int RR = N1 - NF;         // product-1 steps in the remainder block (0, 4, 8, 12): K <= 256 interleaved, step s' covers k = 4 NF + 4 s' + kq
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr bool TRIMMABLE = RR > 0 && KT <= 16;
     constexpr bool IL = TRIMMABLE;
     const int n1_run = N1 - (TRIMMABLE ? a.p1_trim : 0);
-    const int rl = k16_rem_lane<KT, IL>(kq);   // lane part of the k index in the remainder block
+    const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
     const int P = WSTEP ? a.Np : a.Mp;
     const int Q = WSTEP ? a.Mp : a.Np;
     const int nsplit = a.nsplit;
@@ -75,14 +78,14 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     if (!WSTEP) {
         const float *__restrict__ col = U + (size_t)(16 * kq) + (size_t)(q0 + j) * ldu;
 #pragma unroll
-        for (int sb = 0; sb < KT / 4; ++sb)
+        for (int sb = 0; sb < NF / 16; ++sb)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(col + 64 * sb + 4 * e4);
                 ub[16 * sb + 4 * e4] = v[0]; ub[16 * sb + 4 * e4 + 1] = v[1]; ub[16 * sb + 4 * e4 + 2] = v[2]; ub[16 * sb + 4 * e4 + 3] = v[3];
             }
         if (RR > 0) {   // the remainder block: one dword per step (interleaved) or a run of RR (a multiple of 4: 16-B loads)
-            const float *__restrict__ colr = U + (size_t)(64 * (KT / 4) + rl) + (size_t)(q0 + j) * ldu;
+            const float *__restrict__ colr = U + (size_t)(4 * NF + rl) + (size_t)(q0 + j) * ldu;
             if (IL) {
 #pragma unroll
                 for (int sr = 0; sr < RR; ++sr) ub[NF + sr] = colr[4 * sr];
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT, IL>(s) + (k16_in_rem<KT>(s) ? rl : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<NF, IL>(s) + (k16_in_rem<NF>(s) ? rl : 16 * kq)) * ldu];
     }
 
     f32x4 acc[NT];
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
+            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<NF>(e >> 1) ? b1r : b1) + k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
             // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
             float vs_in = 0.f;
             if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }

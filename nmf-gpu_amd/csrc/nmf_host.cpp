@@ -335,10 +335,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         s->Kc = s->Kp;
     }
     s->path = path;
-    // product 1 of the 64-column kernel steps through K four at a time: the steps beyond pad4(K) hold zero padding only (K <= 256:
-    // two workgroups per CU; one wave per SIMD does not earn the branch back, nmf_split16_impl.h)
+    // product 1 of the 64-column kernel steps through K four at a time: the steps beyond pad4(K) hold zero padding only (Kc < 256:
+    // two workgroups per CU, and not BASELINE config 3's own kernel; one wave per SIMD does not earn the branch back, nmf_split16_impl.h)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc <= 256 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc < 256 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
     if (s->p1_trim > 3) s->p1_trim = 3;
     if (getenv("NMF_NO_P1_TRIM")) s->p1_trim = 0;
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H

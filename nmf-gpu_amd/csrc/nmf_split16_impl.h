@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
     constexpr bool TRIMMABLE = false;
     constexpr bool IL = false;
     const int n1_run = N1;
-    const int rl = k16_rem_lane<KT, IL>(kq);   // lane part of the k index in the remainder block
+    const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
     const int b = blockIdx.y;
     if (a.active != nullptr && a.active[b] == 0) return;
     const int P = WSTEP ? a.Np : a.Mp;   // a multiple of 32 NW: every superchunk is whole
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
         }
     } else {
 #pragma unroll
-        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<KT, IL>(s) + (k16_in_rem<KT>(s) ? rl : 16 * kq)) * ldu];
+        for (int s = 0; s < N1; ++s) ub[s] = U[(size_t)(q0 + j) + (size_t)(k16_kconst<NF, IL>(s) + (k16_in_rem<NF>(s) ? rl : 16 * kq)) * ldu];
     }
 
     // The values this wave will update in the epilogue (tiles t = wave, wave + NW, ...: U(16 t + 4 kq + r, q0 + j)), fetched
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<KT>(e >> 1) ? b1r : b1) + k16_kconst<KT, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
+            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<NF>(e >> 1) ? b1r : b1) + k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
             constexpr int E1 = 2 * N1;
             float ar[D];
 #pragma unroll
