@@ -30,7 +30,7 @@ namespace nmf {
 // =====================================================================================
 constexpr int kXt16Floats = 32 * 20;   // per-wave X patch: H-step 16 x 36, W-step 32 x 20 floats
 
-template <int KT, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1, bool GEMM = false>
+template <int KT, bool WSTEP, bool PARTIAL, int DIV, bool CHECK = false, int OCC = 1, bool GEMM = false, int TRIM = 0>
 __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, double *__restrict__ chk_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = 16 * KT;       // what the MFMAs cover (FusedArgs::Kc)
@@ -47,12 +47,15 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
-    // Two workgroups per CU (K <= 256): the remainder block is interleaved and its last steps can be switched off at run time.  With one
-    // wave per SIMD (K > 256; the split kernel) the branch and the compiler-placed MFMAs it requires cost more than the skipped
-    // MFMAs save (measured on the split kernel: -3 % with three steps skipped, -9 .. -12 % with none), so those keep the run map.
-    constexpr bool TRIMMABLE = RR > 0 && KT <= 16;
-    constexpr bool IL = TRIMMABLE;
-    const int n1_run = N1 - (TRIMMABLE ? a.p1_trim : 0);
+    // TRIM = 2, 3 (K <= 256, K % 64 != 0; chosen by the launcher when the caller's K leaves the last two / three steps of product 1 on
+    // zero padding, e.g. K = 100 on the K = 112 kernel: 25 steps instead of 28; K = 200 on the K = 208 kernel: 50 of 52): the remainder block is interleaved over the lane groups so
+    // that its last steps cover the top k indices, and the chain simply ends that many steps early -- compile-time variants, because a
+    // run-time switch (one uniform branch in front of the chain's tail, which forces compiler-placed MFMAs: the copies at the join sit
+    // next to MFMAs whose hazards it must see) cost the untrimmed kernels 0.2 .. 1 % and the split kernel 9 .. 12 %
+    // (profiles/r04_trim_ab.log, r04_small_levers.log).
+    static_assert(TRIM == 0 || ((TRIM == 2 || TRIM == 3) && RR >= 4 && KT <= 16 && !CHECK && !GEMM), "the trimmed chains exist for the K <= 256 half-steps with a remainder block");
+    constexpr bool IL = TRIM > 0;
+    constexpr int N1R = N1 - TRIM;      // product-1 steps that are issued
     const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
     const int P = WSTEP ? a.Np : a.Mp;
     const int Q = WSTEP ? a.Mp : a.Np;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
             float vs_in = 0.f;
             if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
-            constexpr int E1 = 2 * N1;
+            constexpr int E1 = 2 * N1R;
             float ar[D];
 #pragma unroll
             for (int e = 0; e < D; ++e) ar[e] = a1_ld(e);
@@ -209,67 +212,45 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             f32x4 s0, s1;
             constexpr int NLOAD = NST + 2;
             constexpr int G = E1 / (NLOAD + 1);
-            // Position e = 2 s + T of the chain: its MFMA (if COND), then what rides along with it -- the operand ring, the staging of the
-            // next chunk.  A macro, not a lambda: with the body behind a by-reference closure the register allocator spilled (K = 240, 256).
-            // K > 384 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
-            // in front of it and its hazard recogniser cannot see into the asm (nmf_split16.hip, K = 256, came out ~1 % wrong
-            // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
-            // K % 64 != 0: the chain ends in a branch (p1_trim) and the two arms may keep s0 / s1 in different registers: the
-            // copies at the join sit next to the chain's last MFMAs (tools/asm_audit.py flagged every such kernel with asm MFMAs).
-            // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
-            // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: the last 8 NST steps,
-            // which is the second half exactly where KT is even)
-            // (the check also fetches the next X tile, first: it is used first)
-#define NMF_P1_POSITION(e, COND)                                                                                                                     \
-                {                                                                                                                    \
-                    const int s = (e) >> 1;                                                                                          \
-                    if (COND) {                                                                                                      \
-                    if (KT > 24 || TRIMMABLE) {                                                                                         \
-                        if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
-                        else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
-                        else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
-                        else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);                                                      \
-                    }                                                                                                                \
-                    else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));       \
-                    else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));       \
-                    else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));  \
-                    else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));  \
-                    }                                                                                                                \
-                    if (e + D < E1) ar[e % D] = a1_ld(e + D);                                                                        \
-                    if (GEMM || CHECK) {                                                                                             \
-                        constexpr int NLD = GEMM ? NST : NST + 2;                                                                    \
-                        constexpr int GL = (E1 / 2) / (NLD + 1) > 0 ? (E1 / 2) / (NLD + 1) : 1;                                      \
-                        constexpr int ES = E1 - 8 * NST;                                                                             \
-                        if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {                                                            \
-                            const int l = e / GL - 1;                                                                                \
-                            if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);                  \
-                            __builtin_amdgcn_sched_barrier(0);                                                                       \
-                        }                                                                                                            \
-                        if (e >= ES && (e - ES) % 2 == 0 && (e - ES) / 2 < 4 * NST) {                                                \
-                            stage_store_one(vn, (e - ES) / 2);                                                                       \
-                            __builtin_amdgcn_sched_barrier(0);                                                                       \
-                        }                                                                                                            \
-                    } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {                                                          \
-                        const int l = e / G - 1;                                                                                     \
-                        if (l < 2) x_load_one(l); else stage_load_one(l - 2);                                                        \
-                        __builtin_amdgcn_sched_barrier(0);                                                                           \
-                    }                                                                                                                \
+#pragma unroll
+            for (int e = 0; e < E1; ++e) {
+                const int s = e >> 1;
+                if (KT > 24) {
+                    // K > 384 keeps values beyond the accumulator in AGPRs; a copy the compiler makes for an inline-asm MFMA sits right
+                    // in front of it and its hazard recogniser cannot see into the asm (the split kernel at K = 256 came out ~1 % wrong
+                    // that way).  The builtin is an instruction the compiler knows; it costs nothing here (cfg5 shard: 140.9 TFLOP/s).
+                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
+                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
                 }
-            // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
-            // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
-            constexpr int ET = TRIMMABLE ? E1 - 6 : E1;
-#pragma unroll
-            for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
-            if (TRIMMABLE) {
-                if (n1_run == N1) {
-#pragma unroll
-                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)
-                } else {
-#pragma unroll
-                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, ((e) >> 1) < n1_run)
+                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
+                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
+                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
+                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
+                if (e + D < E1) ar[e % D] = a1_ld(e + D);
+                if (GEMM || CHECK) {
+                    // no second product to hide the next chunk's LDS image behind: its global loads go into the first half
+                    // of this chain, its ds_writes between the MFMAs of the second half (one every other MFMA: the last 8 NST steps,
+                    // which is the second half exactly where KT is even)
+                    constexpr int NLD = GEMM ? NST : NST + 2;   // the check also fetches the next X tile (first: it is used first)
+                    constexpr int GL = (E1 / 2) / (NLD + 1) > 0 ? (E1 / 2) / (NLD + 1) : 1;
+                    constexpr int ES = E1 - 8 * NST;
+                    if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {
+                        const int l = e / GL - 1;
+                        if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (e >= ES && (e - ES) % 2 == 0 && (e - ES) / 2 < 4 * NST) {
+                        stage_store_one(vn, (e - ES) / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
+                    const int l = e / G - 1;
+                    if (l < 2) x_load_one(l); else stage_load_one(l - 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#undef NMF_P1_POSITION
             // An MFMA's result needs 12 wait states (8 passes + 4) before anything but an accumulating MFMA touches it, and the compiler
             // pads nothing behind an asm MFMA.  GEMM / CHECK read it at once: twelve nops.  The half-step first issues the eight LDS
             // reads of product 2's operand ring, which count: six nops behind them (tools/asm_audit.py checks every kernel's code).
@@ -413,6 +394,26 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
         note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
+    if constexpr ((16 * KT) % 64 != 0 && KT <= 16) {   // the variants whose product 1 ends two / three steps early (FusedArgs::p1_trim)
+#define NMF_LAUNCH_K16_TRIM(T)                                                                                                        \
+        {                                                                                                                             \
+            if (fast) {                                                                                                               \
+                if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 1, false, OCC, false, T>);             \
+                else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 1, false, OCC, false, T>);          \
+                else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 1, false, OCC, false, T>);          \
+                else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 1, false, OCC, false, T>);                                  \
+            } else {                                                                                                                  \
+                if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 0, false, OCC, false, T>);             \
+                else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 0, false, OCC, false, T>);          \
+                else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 0, false, OCC, false, T>);          \
+                else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 0, false, OCC, false, T>);                                  \
+            }                                                                                                                         \
+            return hipGetLastError();                                                                                                 \
+        }
+        if (a.p1_trim == 3) NMF_LAUNCH_K16_TRIM(3)
+        if (a.p1_trim == 2) NMF_LAUNCH_K16_TRIM(2)
+#undef NMF_LAUNCH_K16_TRIM
+    }
     if (fast) {
         if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 1, false, OCC>);
         else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 1, false, OCC>);

@@ -335,12 +335,13 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         s->Kc = s->Kp;
     }
     s->path = path;
-    // product 1 of the 64-column kernel steps through K four at a time: the steps beyond pad4(K) hold zero padding only (Kc < 256:
-    // two workgroups per CU, and not BASELINE config 3's own kernel; one wave per SIMD does not earn the branch back, nmf_split16_impl.h)
+    // product 1 of the 64-column kernel steps through K four at a time: where the last two or three steps hold zero padding only
+    // (K = 100 on the K = 112 kernel; K = 200 on K = 208) a variant whose chain ends that many steps early runs (nmf_fused16_impl.h: TRIM)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc < 256 && (s->Kc % 64) != 0 && s->Kc > ((K + 3) & ~3)) s->p1_trim = (s->Kc - ((K + 3) & ~3)) / 4;
-    if (s->p1_trim > 3) s->p1_trim = 3;
-    if (getenv("NMF_NO_P1_TRIM")) s->p1_trim = 0;
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc < 256 && (s->Kc % 64) != 0 && !getenv("NMF_NO_P1_TRIM")) {
+        const int zero_steps = (s->Kc - ((K + 3) & ~3)) / 4;
+        s->p1_trim = zero_steps >= 3 ? 3 : (zero_steps == 2 ? 2 : 0);
+    }
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
     // (blockIdx.y = pair: nmf_fused16_impl.h); the 32-column and the wave-pair kernels and the operator path take one pair
     if (batch > 1 && !s->split && !(path == NMF_PATH_FUSED && fused_takes_batch(s->Kp) && s->Mp <= kMaxRowsApplyColsum)) {
@@ -495,7 +496,7 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
     else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
-                                                               s->p1_trim == 1 ? " p1_trim=1" : (s->p1_trim == 2 ? " p1_trim=2" : (s->p1_trim == 3 ? " p1_trim=3" : "")));
+                                                               s->p1_trim == 3 ? " p1_trim=3" : (s->p1_trim == 2 ? " p1_trim=2" : ""));
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     return NMF_OK;
 }

@@ -55,13 +55,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
     constexpr int RR = (K % 64) / 4;    // product-1 steps in the remainder block (0, 4, 8, 12): step s' covers k = 64 (K / 64) + 4 s' + kq
     constexpr int D = kRing < 2 * N1 ? kRing : 2 * N1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
-    // One wave per SIMD has nobody to hide a branch in the MFMA chain behind: the 64-column kernel's run-time trimming of product 1
-    // (FusedArgs::p1_trim; it needs compiler-placed MFMAs and a branch at the end of the chain) measured -3 % here with three steps
-    // skipped and -9 .. -12 % with none.  The remainder block keeps the run map (IL = false: conflict-free at K % 64 = 32) and the
-    // chain stays straight-line inline asm.
-    constexpr bool TRIMMABLE = false;
+    // One wave per SIMD has nobody to hide anything behind: the 64-column kernel's first, run-time form of product-1 trimming (a uniform
+    // branch in front of the chain's tail + compiler-placed MFMAs) measured -3 % here with three steps skipped and -9 .. -12 % with none
+    // (profiles/r04_small_levers.log); this kernel computes on the next multiple of 16 and keeps the run map in the remainder block
+    // (conflict-free at K % 64 = 32) and a straight-line inline-asm chain.
     constexpr bool IL = false;
-    const int n1_run = N1;
     const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
     const int b = blockIdx.y;
     if (a.active != nullptr && a.active[b] == 0) return;
@@ -281,50 +279,29 @@ __global__ __launch_bounds__(64 * NW, OCC) void split_step_kernel_k16(SplitArgs 
             f32x4 s0, s1;
             constexpr int NLOAD = NPC + 2;
             constexpr int G = E1 / (NLOAD + 1);
-            // Position e = 2 s + T of the chain: its MFMA (if COND), then what rides along with it -- the operand ring, the staging of the
-            // next chunk.  A macro, not a lambda: with the body behind a by-reference closure the register allocator spilled (K = 240, 256).
-            // K % 64 != 0: the chain ends in a branch (p1_trim) whose arms may keep s0 / s1 in different registers, and the copies
-            // at the join would sit next to asm MFMAs the compiler cannot see into (tools/asm_audit.py).
-            // K > 128 (one workgroup per CU, one LDS image) keeps part of its operands in AGPRs; the copies the compiler makes for an inline-asm MFMA sit right in
-            // front of it, and the hazard recogniser cannot see into the asm (measured: ~1 % wrong sums in the W-step).
-            // The builtin is an instruction the compiler knows: it places the wait states itself.
-#define NMF_P1_POSITION(e, COND)                                                                                                                     \
-                {                                                                                                                    \
-                    const int s = (e) >> 1;                                                                                          \
-                    if (COND) {                                                                                                      \
-                    if (KT > 8 || TRIMMABLE) {                                                                                          \
-                        if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
-                        else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));                                 \
-                        else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);                                                      \
-                        else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);                                                      \
-                    }                                                                                                                \
-                    else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));       \
-                    else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));       \
-                    else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));  \
-                    else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));  \
-                    }                                                                                                                \
-                    if (e + D < E1) ar[e % D] = a1_ld(e + D);                                                                        \
-                    if (!LAST && e >= G && e % G == 0 && e / G - 1 < NLOAD) {                                                        \
-                        const int l = e / G - 1;                                                                                     \
-                        if (l < NPC) stage_load_one(l); else x_load_one(l - NPC);                                                    \
-                        __builtin_amdgcn_sched_barrier(0);                                                                           \
-                    }                                                                                                                \
+#pragma unroll
+            for (int e = 0; e < E1; ++e) {
+                const int s = e >> 1;
+                if (KT > 8) {
+                    // K > 128 (one workgroup per CU, one LDS image) keeps part of its operands in AGPRs; the copies the compiler makes for an
+                    // inline-asm MFMA sit right in front of it, and the hazard recogniser cannot see into the asm (measured: ~1 % wrong sums in
+                    // the W-step).  The builtin is an instruction the compiler knows: it places the wait states itself.
+                    if (e == 0)      s0 = NMF_MFMA16(ar[0], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e == 1) s1 = NMF_MFMA16(ar[1], ub[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    else if (e & 1)  s1 = NMF_MFMA16(ar[e % D], ub[s], s1);
+                    else             s0 = NMF_MFMA16(ar[e % D], ub[s], s0);
                 }
-            // Where K is not a multiple of 64 the last three steps (six positions) are the ones p1_trim may switch off: they get a
-            // copy of their own behind ONE uniform branch, so that the untrimmed chain stays straight-line code
-            constexpr int ET = TRIMMABLE ? E1 - 6 : E1;
-#pragma unroll
-            for (int e = 0; e < ET; ++e) NMF_P1_POSITION(e, true)
-            if (TRIMMABLE) {
-                if (n1_run == N1) {
-#pragma unroll
-                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, true)
-                } else {
-#pragma unroll
-                    for (int e = ET; e < E1; ++e) NMF_P1_POSITION(e, ((e) >> 1) < n1_run)
+                else if (e == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s0) : "v"(ar[0]), "v"(ub[0]));
+                else if (e == 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(s1) : "v"(ar[1]), "v"(ub[0]));
+                else if (e & 1)  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(ar[e % D]), "v"(ub[s]));
+                else             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(ar[e % D]), "v"(ub[s]));
+                if (e + D < E1) ar[e % D] = a1_ld(e + D);
+                if (!LAST && e >= G && e % G == 0 && e / G - 1 < NLOAD) {
+                    const int l = e / G - 1;
+                    if (l < NPC) stage_load_one(l); else x_load_one(l - NPC);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#undef NMF_P1_POSITION
             if (OCC > 1) __builtin_amdgcn_s_setprio(0);
             // ---- first operands of product 2, then the quotient in one VALU block
             const lds_float *b2 = (const lds_float *)vb + p2_off;

@@ -56,18 +56,26 @@ K16_KTS = tuple(range(3, 17)) + tuple(range(18, 33, 2))   # every multiple of 16
 
 
 def test_every_instantiation_of_the_64_column_kernel(ng, oracle, recording):
-    """fused_step_kernel_k16<KT, WSTEP, PARTIAL, DIV, CHECK, OCC, GEMM>: KT = K/16 in 3..16 (OCC = 2) and 18, 20, .. 32 (OCC = 1),
+    """fused_step_kernel_k16<KT, WSTEP, PARTIAL, DIV, CHECK, OCC, GEMM, TRIM>: KT = K/16 in 3..16 (OCC = 2) and 18, 20, .. 32 (OCC = 1),
     both half-steps, in-place and partial-slab epilogues, both quotients, and the CHECK instantiation of every KT.  The odd KT
-    (K = 48, 80, ... 240: a remainder block in the k map, a zero-padded half piece in the LDS image) are the round-4 additions."""
+    (K = 48, 80, ... 240: a remainder block in the k map, a zero-padded half piece in the LDS image) are the round-4 additions, as
+    are the TRIM = 2, 3 variants (K <= 256, K % 64 != 0): a caller's K that leaves the last two / three steps of product 1 on zero
+    padding (K = 16 KT - 8 / - 12 here: K = 100 on the K = 112 kernel) launches the chain that ends that many steps early."""
     seen = set()
     for kt, ns, fd in itertools.product(K16_KTS, (1, 2), (0, 1)):
         _half_steps(ng, oracle, 160, 208, 16 * kt, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    trim_kts = [kt for kt in K16_KTS if kt <= 16 and kt % 4 != 0]
+    for kt, ns, fd, zero_steps in itertools.product(trim_kts, (1, 2), (0, 1), (3, 2)):
+        _half_steps(ng, oracle, 160, 208, 16 * kt - 4 * zero_steps, seen, split_kernel=-1, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
     want = set()
     for kt in K16_KTS:
         occ = "2" if kt <= 16 else "1"
         for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
-            want.add(("fused_step_kernel_k16", (str(kt), w, p, d, "false", occ, "false")))
-        want.add(("fused_step_kernel_k16", (str(kt), "false", "false", "0", "true", occ, "false")))
+            want.add(("fused_step_kernel_k16", (str(kt), w, p, d, "false", occ, "false", "0")))
+            if kt in trim_kts:
+                want.add(("fused_step_kernel_k16", (str(kt), w, p, d, "false", occ, "false", "3")))
+                want.add(("fused_step_kernel_k16", (str(kt), w, p, d, "false", occ, "false", "2")))
+        want.add(("fused_step_kernel_k16", (str(kt), "false", "false", "0", "true", occ, "false", "0")))
     assert want <= seen, sorted(want - seen)
 
 
