@@ -39,21 +39,23 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     constexpr int VBUF = KS * kLdv;
     constexpr int N1 = 4 * KT;       // product-1 steps per 16-row tile
     constexpr int NT = KT;           // 16 x 16 accumulator tiles
-    // Treating the last WHOLE block of 64 as a trimmable remainder too (so that K = 50 or 120 skip their zero steps) was measured and
-    // dropped: K = 50 gained 5 %, but K = 64 itself lost 2.5 % and K = 192 1 % (every product-1 LDS read of that block 2-way conflicted,
-    // compiler-placed MFMAs, the branch), and powers of two are the common case (profiles/r04_last_block_interleave.log).
-    constexpr int NF = 16 * (KT / 4);   // product-1 steps in the whole 64-blocks of k (run map)
-    constexpr int RR = N1 - NF;         // product-1 steps in the remainder block (0, 4, 8, 12): K <= 256 interleaved, step s' covers k = 4 NF + 4 s' + kq
+    // The remainder block of product 1: the steps beyond the whole blocks of 64 -- or, in a TRIM variant of a K that is a multiple of
+    // 64 (K = 50 on the K = 64 kernel), the last whole block (16 steps), so that those variants have something to trim.  The TRIM = 0
+    // kernels of K = 64 / 128 / 192 / 256 keep the run map throughout: interleaving their last block cost K = 64 2.5 % when it was
+    // tried on the one kernel that served both (profiles/r04_last_block_interleave.log).
+    constexpr bool LASTIL = TRIM > 0 && KT % 4 == 0;
+    constexpr int NF = LASTIL ? 16 * (KT / 4 - 1) : 16 * (KT / 4);   // product-1 steps in the whole 64-blocks of k that use the run map
+    constexpr int RR = N1 - NF;         // product-1 steps in the remainder block (0, 4, 8, 12; 16 under LASTIL)
     constexpr int D = kRing;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, kq = lane >> 4;
     // the last p1_trim (0 .. 3) steps of the remainder block cover zero padding only (K_true <= K - 4 p1_trim): skipped
-    // TRIM = 2, 3 (K <= 256, K % 64 != 0; chosen by the launcher when the caller's K leaves the last two / three steps of product 1 on
+    // TRIM = 2, 3 (K <= 256; chosen by the launcher when the caller's K leaves the last two / three steps of product 1 on
     // zero padding, e.g. K = 100 on the K = 112 kernel: 25 steps instead of 28; K = 200 on the K = 208 kernel: 50 of 52): the remainder block is interleaved over the lane groups so
     // that its last steps cover the top k indices, and the chain simply ends that many steps early -- compile-time variants, because a
     // run-time switch (one uniform branch in front of the chain's tail, which forces compiler-placed MFMAs: the copies at the join sit
     // next to MFMAs whose hazards it must see) cost the untrimmed kernels 0.2 .. 1 % and the split kernel 9 .. 12 %
     // (profiles/r04_trim_ab.log, r04_small_levers.log).
-    static_assert(TRIM == 0 || ((TRIM == 2 || TRIM == 3) && RR >= 4 && KT <= 16 && !CHECK && !GEMM), "the trimmed chains exist for the K <= 256 half-steps with a remainder block");
+    static_assert(TRIM == 0 || ((TRIM == 2 || TRIM == 3) && RR >= 4 && KT <= 16 && !CHECK && !GEMM), "the trimmed chains exist for the K <= 256 half-steps");
     constexpr bool IL = TRIM > 0;
     constexpr int N1R = N1 - TRIM;      // product-1 steps that are issued
     const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
@@ -394,7 +396,7 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
         note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
-    if constexpr ((16 * KT) % 64 != 0 && KT <= 16) {   // the variants whose product 1 ends two / three steps early (FusedArgs::p1_trim)
+    if constexpr (KT <= 16) {   // the variants whose product 1 ends two / three steps early (FusedArgs::p1_trim)
 #define NMF_LAUNCH_K16_TRIM(T)                                                                                                        \
         {                                                                                                                             \
             if (fast) {                                                                                                               \

@@ -338,7 +338,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // product 1 of the 64-column kernel steps through K four at a time: where the last two or three steps hold zero padding only
     // (K = 100 on the K = 112 kernel; K = 200 on K = 208) a variant whose chain ends that many steps early runs (nmf_fused16_impl.h: TRIM)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc < 256 && (s->Kc % 64) != 0 && !getenv("NMF_NO_P1_TRIM")) {
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc <= 256 && !getenv("NMF_NO_P1_TRIM")) {
         const int zero_steps = (s->Kc - ((K + 3) & ~3)) / 4;
         s->p1_trim = zero_steps >= 3 ? 3 : (zero_steps == 2 ? 2 : 0);
     }

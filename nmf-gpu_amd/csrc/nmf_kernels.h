@@ -34,7 +34,7 @@ struct FusedArgs {
     int Mp, Np, Kp;
     int Kc = 0;               // 16-column kernel: the K its MFMAs cover, a multiple of 16 with Kp == pad32(Kc) (rows / columns Kc .. Kp - 1 of
                               //    the factors are zero padding); 0 = Kp.  The other families compute on Kp.
-    int p1_trim = 0;          // 64-column kernel, Kc < 256, Kc % 64 != 0: 2 / 3 = the last two / three steps of product 1 cover zero padding
+    int p1_trim = 0;          // 64-column kernel, Kc <= 256: 2 / 3 = the last two / three steps of product 1 cover zero padding
                               //    only (the caller's K <= Kc - 8 / Kc - 12): launch the variant whose chain ends that early (TRIM); 0 = the full chain
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place

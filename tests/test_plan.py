@@ -33,8 +33,10 @@ import pytest
     ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=20> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 37), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=2"),      # product 1 on 40 of 48
     ((4096, 65536, 36), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=3"),       # product 1 on 36 of 48
-    ((4096, 65536, 250), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),            # K % 64 == 0 kernels have no trimmable block
-    ((4096, 65536, 50), 1, "fused_step_kernel_k16<KT=4> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 250), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),            # one zero step only: the full chain
+    ((4096, 65536, 244), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8) p1_trim=3"),
+    ((4096, 65536, 50), 1, "fused_step_kernel_k16<KT=4> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=3"),       # product 1 on 52 of 64: the last whole block interleaved in the TRIM variants
+    ((4096, 65536, 120), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,8) p1_trim=2"),
     ((4096, 350, 100), 1, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
     ((4096, 350, 200), 1, "split_step_kernel_k16<KT=13> Mp=4096 Np=384 Kp=224 splits(h,w)=(11,1) batch=1"),
     ((4096, 350, 100), 16, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
