@@ -101,7 +101,7 @@ def test_sharded_main_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,G", [(1024, 4096, 64, 2), (1024, 4096, 64, 3), (512, 700, 256, 4), (512, 3000, 100, 3), (1024, 9000, 160, 2)])
+@pytest.mark.parametrize("M,N,K,G", [(1024, 4096, 64, 2), (1024, 4096, 64, 3), (512, 700, 256, 4), (512, 3000, 100, 3)])
 def test_in_library_multi_device_driver_with_emulated_shards(oracle, tmp_path, M, N, K, G):
     """multi-GPU is callee-internal.  A plain C++ main (examples/sharded_main.cpp, built with g++ against the
     header and the .so) calls update_div_ex once on host matrices; the library shards the columns over G ranks -- one host
@@ -110,7 +110,8 @@ def test_in_library_multi_device_driver_with_emulated_shards(oracle, tmp_path, M
     the per-rank loop and the solver's sharded W-step are the production code.  200 iterations against the oracle at 1e-5
     (cfg2 shape: BASELINE config 2), replicas of W bit-identical, and G = 1-vs-G within the all-reduce's reordering.
     K = 100 (split kernel per rank, computing on 112 in factors padded to 128: the all-reduce operand carries zero padding rows)
-    and K = 160 (64-column kernel per rank) are round 4's ranks between the powers of two."""
+    is one of round 4's ranks between the powers of two; the 64-column kernel under sharding at such a rank:
+    tests/test_gpu_multi.py::test_sharded_64_column_kernel_at_a_rank_between_the_powers_of_two."""
     exe = _build_example(tmp_path, "sharded_main")
     assert _run("generate", "--M", str(M), "--N", str(N), "--K", str(K), cwd=tmp_path).returncode == 0
     r = subprocess.run([str(exe), str(tmp_path), str(G), "emulate"], capture_output=True, text=True, timeout=600)
@@ -121,10 +122,7 @@ def test_in_library_multi_device_driver_with_emulated_shards(oracle, tmp_path, M
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
     eW = oracle.relF(oracle.read_bin(str(tmp_path / "Wout.bin")), Wr)
     eH = oracle.relF(oracle.read_bin(str(tmp_path / "Hout.bin")), Hr)
-    # 1e-5 on the small shapes; the 9000-column one sits at 1.1e-5 after 200 iterations (summation-order drift grows with the
-    # reduction length: cfg3 reaches 1.08e-5); north_star's gate is 1e-4
-    tol = 2e-5 if N > 5000 else 1e-5
-    assert eW < tol and eH < tol, (eW, eH)
+    assert eW < 1e-5 and eH < 1e-5, (eW, eH)
 
 
 @pytest.mark.gpu

@@ -10,6 +10,11 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _rand_f(rng, rows, cols):
+    """uniform [0, 1) fp32, column-major, without the transposing copy np.asfortranarray(rng.random((rows, cols))) makes (seconds per GiB)"""
+    return rng.random((cols, rows), dtype=np.float32).T
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -172,8 +177,8 @@ def test_rccl_library_identity_is_reported_and_checked(ng):
 # ------------------------------------------------------------------------------ replicas-only restarts
 def _pairs(M, N, K, R, seed):
     rng = np.random.default_rng(seed)
-    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
-    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    Ws = [_rand_f(rng, M, K) for _ in range(R)]
+    Hs = [_rand_f(rng, K, N) for _ in range(R)]
     return Ws, Hs
 
 
@@ -292,3 +297,17 @@ def test_concurrent_ranks_each_with_an_rccl_communicator_capture_and_replay_thei
         X, W, H = probs[i]
         Wr, Hr, _, klr = oracle.update_div(W, H, X, 1e-30, 80, 40)
         assert oracle.relF(Wt, Wr) < 1e-5 and oracle.relF(Ht, Hr) < 1e-5 and np.allclose(rt["kl"], klr, rtol=2e-5), (M, N, K)
+
+
+@pytest.mark.parametrize("K,G", [(160, 2), (100, 3)])
+def test_sharded_64_column_kernel_at_a_rank_between_the_powers_of_two(ng, oracle, K, G):
+    """The in-library driver with emulated shards where every rank runs the 64-column kernel (split_kernel = -1) at a K that is not a
+    power of two: K = 160 (KT = 10, factors padded to 160) and K = 100 (KT = 7 with three steps of product 1 trimmed, factors padded
+    to 128: the all-reduce operand and the slabs carry zero padding rows).  60 iterations against the oracle, replicas identical."""
+    M, N = 512, 2048
+    X, W, H = oracle.gen_problem(M, N, K, seed=41)
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=60, emulate_shards=G, split_kernel=-1)
+    assert r["n_shards"] == G and r["w_replicas_identical"] == 1 and r["iterations"] == 60
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 60, 25)
+    assert oracle.relF(Wm.mat, Wr) < 1e-5 and oracle.relF(Hm.mat, Hr) < 1e-5

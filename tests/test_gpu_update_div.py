@@ -12,6 +12,11 @@ import pytest
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
+
+
+def _rand_f(rng, rows, cols):
+    """uniform [0, 1) fp32, column-major, without the transposing copy np.asfortranarray(rng.random((rows, cols))) makes (seconds per GiB)"""
+    return rng.random((cols, rows), dtype=np.float32).T
 TOL = 1e-4
 
 
@@ -223,9 +228,9 @@ def test_full_size_properties_cfg3(ng, oracle, M, N, K):
     the KL divergence decreases monotonically.  Plus parity with the oracle after K_par = 2
     iterations (the CPU needs ~0.55 TFLOP per iteration here)."""
     rng = np.random.default_rng(0)
-    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    X = _rand_f(rng, M, N)
+    W = _rand_f(rng, M, K)
+    H = _rand_f(rng, K, N)
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
     kl0, _ = s.check()
@@ -315,9 +320,9 @@ def test_gpu_against_an_fp64_evaluation_over_long_reductions(ng, M, N, K, kw):
     iterations, relF <= 2e-5, and no common scale factor between the factors (|scale| < 2e-6) -- the signature of a biased
     long reduction, which is what the first cfg3 x 200 comparison exposed in the oracle's fast arrangement (round 3)."""
     rng = np.random.default_rng(7)
-    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    X = _rand_f(rng, M, N)
+    W = _rand_f(rng, M, K)
+    H = _rand_f(rng, K, N)
     eps, iters = float(ng.EPS), 20
     W64, H64, X64 = np.maximum(W.astype(np.float64), eps), np.maximum(H.astype(np.float64), eps), np.maximum(X.astype(np.float64), eps)
     for _ in range(iters):
@@ -394,8 +399,8 @@ def test_cfg3_200_iterations_kl_monotone(ng):
     M, N, K = 4096, 65536, 256
     rng = np.random.default_rng(3)
     s = ng.Solver(M, N, K)
-    s.upload(np.asfortranarray(rng.random((M, K), dtype=np.float32)), np.asfortranarray(rng.random((K, N), dtype=np.float32)),
-             np.asfortranarray(rng.random((M, N), dtype=np.float32)))
+    s.upload(_rand_f(rng, M, K), _rand_f(rng, K, N),
+             _rand_f(rng, M, N))
     r = s.run(1e-30, 200, 25)            # a threshold no decreasing sequence reaches: checks on, no early stop
     W, H = s.download()
     s.close()
@@ -412,9 +417,9 @@ def test_cfg5_tall_skinny_r512(ng, oracle):
     M, N, K = 8192, 131072, 512
     rng = np.random.default_rng(5)
     ns = N // 8
-    X = np.asfortranarray(rng.random((M, ns), dtype=np.float32))      # the shard's columns only
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, ns), dtype=np.float32))
+    X = _rand_f(rng, M, ns)      # the shard's columns only
+    W = _rand_f(rng, M, K)
+    H = _rand_f(rng, K, ns)
     s = ng.Solver(M, ns, K)
     s.upload(W, np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns]))
     s.iterate(1)
@@ -505,9 +510,9 @@ def test_full_size_properties_cfg4_shard_shape(ng):
     oracle in a test, so only the size-independent invariants of the KL update are checked (see the cfg3 test)."""
     M, N, K = 4096, 262144, 256
     rng = np.random.default_rng(1)
-    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    X = _rand_f(rng, M, N)
+    W = _rand_f(rng, M, K)
+    H = _rand_f(rng, K, N)
     s = ng.Solver(M, N, K)
     s.upload(W, H, X)
     kl0, _ = s.check()
@@ -537,7 +542,8 @@ def test_cfg4_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, ora
     checked against the pinned loop on one shard's columns."""
     import time
     M, N, K, G, KPAR = 4096, 262144, 256, 8, 3
-    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    rng = np.random.default_rng(4)
+    X, W, H = _rand_f(rng, M, N), _rand_f(rng, M, K), _rand_f(rng, K, N)
     ns = N // G
     Hs, Xs = np.asfortranarray(H[:, :ns]), np.asfortranarray(X[:, :ns])
     W1r, H1r, _, _ = oracle.update_div(W, Hs, Xs, 0.0, 1, 25)
@@ -573,7 +579,8 @@ def test_cfg5_full_size_against_the_oracle_unsharded_and_as_eight_shards(ng, ora
     through the in-library driver with emulated ranks (16 MiB all-reduce operand per iteration)."""
     import time
     M, N, K, G, KPAR = 8192, 131072, 512, 8, 2
-    X, W, H = oracle.gen_problem(M, N, K, seed=0)
+    rng = np.random.default_rng(5)
+    X, W, H = _rand_f(rng, M, N), _rand_f(rng, M, K), _rand_f(rng, K, N)
     t0 = time.time()
     Wr, Hr = oracle.update_div_fast(W, H, X, KPAR)
     dt = time.time() - t0
@@ -598,8 +605,8 @@ def test_multi_restart_picks_lowest_kl(ng, oracle):
     M, N, K, R = 128, 200, 16, 4
     X, _, _ = oracle.gen_problem(M, N, K, seed=0)
     rng = np.random.default_rng(5)
-    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
-    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    Ws = [_rand_f(rng, M, K) for _ in range(R)]
+    Hs = [_rand_f(rng, K, N) for _ in range(R)]
     Wm, Hm = [ng.Matrix(w) for w in Ws], [ng.Matrix(h) for h in Hs]
     best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=30)
     ref = []
@@ -699,10 +706,10 @@ def test_range_guarded_division_is_bit_identical_to_the_full_sequence(ng, M, N, 
     """Default division (range scaling skipped for waves whose operands are all in [EPS, 2^60]) against
     nmf_opts.fast_divide = -1 (always the complete IEEE sequence): the same bits, not a tolerance."""
     rng = np.random.default_rng(11)
-    X = np.asfortranarray(rng.random((M, N), dtype=np.float32))
+    X = _rand_f(rng, M, N)
     X[rng.random((M, N)) < 0.01] = 0.0                       # exact zeros are clamped to EPS at upload
-    W = np.asfortranarray(rng.random((M, K), dtype=np.float32))
-    H = np.asfortranarray(rng.random((K, N), dtype=np.float32))
+    W = _rand_f(rng, M, K)
+    H = _rand_f(rng, K, N)
     outs = []
     for fd in (0, -1):
         s = ng.Solver(M, N, K, fast_divide=fd)
@@ -771,8 +778,8 @@ def test_restart_lanes_equal_sequential_restarts(ng, oracle, thresh):
     M, N, K, R = 512, 1000, 30, 7                       # 7 restarts over 3 lanes: two full waves and a ragged one
     X, _, _ = oracle.gen_problem(M, N, K, seed=2)
     rng = np.random.default_rng(9)
-    Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
-    Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+    Ws = [_rand_f(rng, M, K) for _ in range(R)]
+    Hs = [_rand_f(rng, K, N) for _ in range(R)]
     runs = []
     for lanes in (1, 3, 0):
         Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
