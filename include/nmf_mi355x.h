@@ -283,6 +283,10 @@ typedef struct nmf_comm nmf_comm;
 int  nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]);
 int  nmf_comm_init_rank(nmf_comm **c, const unsigned char id[NMF_COMM_ID_BYTES], int rank, int nranks);
 void nmf_comm_destroy(nmf_comm *c);
+/* Collective (every rank of the communicator calls it): one 8-float all-reduce waited for with a deadline (timeout_s <= 0:
+ * NMF_COMM_TIMEOUT_S, default 30 s) and checked.  NMF_OK, or NMF_ERR_COMM after the communicator has been aborted: a launcher that
+ * can still fall back to another all-reduce (bench.py: torch.distributed) probes before it commits to this one. */
+int  nmf_comm_probe(nmf_comm *c, double timeout_s);
 /* one line: version and path of the RCCL library actually loaded, and the rccl.h version this library was compiled against
  * (a different major version is refused at load) */
 int  nmf_comm_library_info(char *buf, int buflen);

@@ -120,6 +120,7 @@ _SIGS = [
     ("nmf_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("nmf_comm_init_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
     ("nmf_comm_destroy", None, [C.c_void_p]),
+    ("nmf_comm_probe", C.c_int, [C.c_void_p, C.c_double]),
     ("nmf_comm_library_info", C.c_int, [C.c_char_p, C.c_int]),
     ("nmf_worth_sharding", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("nmf_plan_describe", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_opts), C.c_char_p, C.c_int]),
@@ -395,6 +396,10 @@ class Comm:
         self._h = C.c_void_p()
         _chk(lib().nmf_comm_init_rank(C.byref(self._h), uid, rank, nranks))
         self.rank, self.nranks = rank, nranks
+
+    def probe(self, timeout_s: float = 0.0) -> None:
+        """collective: one small all-reduce with a deadline, checked; raises NmfError if the communicator does not work"""
+        _chk(lib().nmf_comm_probe(self._h, float(timeout_s)))
 
     def close(self):
         if self._h:

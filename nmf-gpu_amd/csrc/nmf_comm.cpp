@@ -222,6 +222,33 @@ extern "C" void nmf_comm_destroy(nmf_comm *c) {
     delete c;
 }
 
+// One small all-reduce through the communicator, waited for with a deadline: every rank contributes 1.0 in eight floats and must read
+// back the number of ranks.  The first collective of a communicator is where RCCL brings up its transports and where a peer that never
+// arrives shows: a caller that can still choose another all-reduce (bench.py: torch.distributed) probes before it commits.  Collective:
+// every rank of the communicator must call it.  On expiry the communicator (group) is aborted, as with every other wait.
+extern "C" int nmf_comm_probe(nmf_comm *c, double timeout_s) {
+    if (!c) return NMF_ERR_ARG;
+    if (timeout_s <= 0.0) timeout_s = nmf_comm_timeout_s();
+    float *d = nullptr;
+    hipStream_t st = nullptr;
+    if (hipMalloc((void **)&d, 8 * sizeof(float)) != hipSuccess) return NMF_ERR_NOMEM;
+    int rc = NMF_OK;
+    const float ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    float back[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(d); return NMF_ERR_HIP; }
+    if (hipMemcpyAsync(d, ones, sizeof ones, hipMemcpyHostToDevice, st) != hipSuccess) rc = NMF_ERR_HIP;
+    if (rc == NMF_OK) rc = nmf_comm_allreduce_f32(c, d, 8, st);
+    if (rc == NMF_OK) rc = nmf_comm_wait(c, st, timeout_s, "the probe all-reduce");
+    if (rc == NMF_OK && hipMemcpyAsync(back, d, sizeof back, hipMemcpyDeviceToHost, st) != hipSuccess) rc = NMF_ERR_HIP;
+    if (rc == NMF_OK && hipStreamSynchronize(st) != hipSuccess) rc = NMF_ERR_HIP;
+    if (rc == NMF_OK)
+        for (float v : back)
+            if (v != (float)c->nranks) { fprintf(stderr, "nmf_comm: rank %d: the probe all-reduce returned %g, expected %d\n", c->rank, (double)v, c->nranks); rc = NMF_ERR_COMM; break; }
+    (void)hipStreamDestroy(st);
+    (void)hipFree(d);
+    return rc;
+}
+
 extern "C" int nmf_comm_library_info(char *buf, int buflen) {
     if (!buf || buflen <= 0) return NMF_ERR_ARG;
     if (!load_api()) { snprintf(buf, (size_t)buflen, "RCCL not loadable"); return NMF_ERR_COMM; }

@@ -49,7 +49,7 @@ def negotiate_comm(dist, torch, rank: int, world: int, unique_id: Callable, make
     """Set up one in-library communicator per rank -- rank 0 makes the 128-byte id (``unique_id()``), torch broadcasts it,
     every rank calls ``make_comm(id_bytes, rank, world)`` -- such that EVERY rank runs the same sequence of torch collectives
     whether or not something fails: rank 0 always broadcasts (a zeroed id when it could not make one) and an ok flag is
-    MIN-reduced after each stage, so a rank that fails early never leaves the others waiting in a different collective
+    MIN-reduced after each stage (id, communicator, a probe all-reduce through it), so a rank that fails early never leaves the others waiting in a different collective
     (round-2 advisor: a rank raising before the broadcast deadlocked the rest until the process-group time-out).
     Returns (comm, "") on every rank, or (None, reason) on every rank; a communicator made by a rank whose peers failed is
     closed before returning."""
@@ -73,6 +73,14 @@ def negotiate_comm(dist, torch, rank: int, world: int, unique_id: Callable, make
             comm = make_comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
         except Exception as e:      # ncclCommInitRank failure (e.g. two ranks on one device)
             ok, why = False, str(e)
+        ok = all_ok(ok)
+    if ok and hasattr(comm, "probe"):
+        # the communicator's FIRST collective, with a deadline (NMF_COMM_TIMEOUT_S): transports come up here and a peer that cannot
+        # be reached shows here -- while every rank can still agree on the other all-reduce
+        try:
+            comm.probe()
+        except Exception as e:
+            ok, why = False, "probe all-reduce: " + str(e)
         ok = all_ok(ok)
     if not ok:
         if comm is not None:

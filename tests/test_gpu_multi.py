@@ -311,3 +311,14 @@ def test_sharded_64_column_kernel_at_a_rank_between_the_powers_of_two(ng, oracle
     assert r["n_shards"] == G and r["w_replicas_identical"] == 1 and r["iterations"] == 60
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 60, 25)
     assert oracle.relF(Wm.mat, Wr) < 1e-5 and oracle.relF(Hm.mat, Hr) < 1e-5
+
+
+def test_probe_all_reduce_of_a_communicator(ng):
+    """nmf_comm_probe: the communicator's first collective, with a deadline and a checked result -- what bench.py's negotiation runs on
+    every rank before it commits to the in-library all-reduce (a one-rank communicator here; every rank must call it)."""
+    c = ng.Comm(ng.Comm.unique_id(), 0, 1)
+    try:
+        c.probe()
+        c.probe(5.0)
+    finally:
+        c.close()
