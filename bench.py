@@ -206,6 +206,32 @@ def main():
     else:
         s = ng.Solver(M, Nloc, K, use_graph=not args.no_graph, device=local_rank, comm=comm)
     s.upload(W, H, X)
+    if comm is not None:
+        # The first iterations through the in-library communicator -- graph capture with the all-reduce inside, replay, an all-reduced
+        # check (which waits with the communicator's deadline, NMF_COMM_TIMEOUT_S) -- while every rank can still agree on the other path:
+        # N > 1 ranks over xGMI have never run before the driver's scaling run, and a bench line from torch.distributed beats none.
+        ok, why = True, ""
+        try:
+            s.prepare(args.steps)
+            s.iterate(max(1, args.warmup))
+            s.check()
+        except Exception as e:
+            ok, why = False, str(e)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            print(f"bench.py rank {rank}: the first iterations over the in-library communicator failed ({why or 'on another rank'}); using torch.distributed", file=sys.stderr)
+            if args.comm == "rccl":
+                raise SystemExit(f"bench.py rank {rank}: --comm rccl: the in-library RCCL all-reduce does not work here ({why or 'another rank failed'})")
+            try:
+                s.close(); comm.close()
+            except Exception:
+                pass
+            comm, comm_used = None, "torch"
+            shard = ng.GpuShard(M, Nloc, K, device=local_rank)
+            s = shard.solver
+            loop = ng.ShardedLoop(shard, shard.allreduce_sum, shard.allreduce_scalars)
+        s.upload(W, H, X)      # the timed run starts from the same factors either way
     del X
 
     def step(n):

@@ -204,6 +204,7 @@ extern "C" int nmf_comm_init_rank(nmf_comm **out, const unsigned char id[NMF_COM
         delete c;
         return NMF_ERR_COMM;
     }
+    arm_fault(c);
     *out = c;
     return NMF_OK;
 }

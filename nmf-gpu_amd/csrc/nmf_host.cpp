@@ -400,6 +400,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
     NMFCHK(plan_solver(s, M, N, K, o, batch, split_batch));
     const int path = s->path;
     s->comm = (nmf_comm *)o.comm;
+    if (s->comm) s->block_budget_s = nmf_comm_timeout_s();   // waits outside solver_run (a check after iterate()) carry the communicator's deadline too
     if (o.stream) { s->stream = (hipStream_t)o.stream; s->own_stream = false; }
     else { NMFCHK(acquire_stream(&s->stream)); s->own_stream = true; s->stream_device = -1; (void)hipGetDevice(&s->stream_device); }
 
