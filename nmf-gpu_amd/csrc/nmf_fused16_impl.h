@@ -463,7 +463,7 @@ hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int
 
 // Every KT with a kernel: all multiples of 16 from K = 48 to 256, all multiples of 32 above, in the four groups
 // nmf_fused16_inst.hip is compiled in (balanced by code size).  X(KT) is applied to each.
-#define NMF_K16_GROUP0(X) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32)
+#define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32)
 #define NMF_K16_GROUP1(X) X(11) X(12) X(13) X(14) X(30)
 #define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28)
 #define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26)

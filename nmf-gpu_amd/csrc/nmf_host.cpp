@@ -276,7 +276,10 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     // 2^23, +3 % at 2^24, -4 % at 2^25); K = 144 .. 224 ahead through 2^23 (K = 160: +26 / +12 %, then -9 % at 2^24; K = 224: +3 %
     // at 2^23); K = 256 behind from 2^23 on.
     const int kc = split_compute_k(K);
-    const int lg = kc <= 32 ? 26 : (kc <= 112 ? 24 : (kc <= 224 ? 23 : 22));
+    // K <= 32: against the 32-column kernel the split kernel stayed ahead through 2^25; against the 64-column kernel's K = 32
+    // instantiation, which serves K <= 32 since round 4, it leads by 16 % at 2^23, ties at 2^24 and trails by 2-10 % beyond
+    // (profiles/r04_crossover_k32.log)
+    const int lg = kc <= 112 ? 24 : (kc <= 224 ? 23 : 22);
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
@@ -321,8 +324,8 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     s->Mp = s->split ? ((M + 127) & ~127) : pad32(M);
     s->Np = s->split ? ((N + 127) & ~127) : pad32(N);
     if (s->split) path = NMF_PATH_FUSED;
-    // the 16x16x4 kernel (K > 256) addresses the streamed factor with 32-bit lane offsets and has no 64-bit fallback
-    const bool k16_too_tall = fused_pad_k(K) >= 64 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
+    // the 16x16x4 kernels address the streamed factor with 32-bit lane offsets and have no 64-bit fallback
+    const bool k16_too_tall = fused_pad_k(K) >= 32 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
     if (path == NMF_PATH_AUTO) path = (fused_pad_k(K) && !k16_too_tall) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
@@ -338,7 +341,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // product 1 of the 64-column kernel steps through K four at a time: where the last two or three steps hold zero padding only
     // (K = 100 on the K = 112 kernel; K = 200 on K = 208) a variant whose chain ends that many steps early runs (nmf_fused16_impl.h: TRIM)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 48 && s->Kc <= 256 && !getenv("NMF_NO_P1_TRIM")) {
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 32 && s->Kc <= 256 && !getenv("NMF_NO_P1_TRIM")) {
         const int zero_steps = (s->Kc - ((K + 3) & ~3)) / 4;
         s->p1_trim = zero_steps >= 3 ? 3 : (zero_steps == 2 ? 2 : 0);
     }
@@ -496,7 +499,7 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
     else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
-    else if (s->Kp >= 64 && !getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
+    else if (!getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
                                                                s->p1_trim == 3 ? " p1_trim=3" : (s->p1_trim == 2 ? " p1_trim=2" : ""));
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     return NMF_OK;

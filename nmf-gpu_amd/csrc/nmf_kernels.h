@@ -52,8 +52,8 @@ struct FusedArgs {
                               //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
 };
 hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream);
-// the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 48 <= Kc <= 512, every multiple of 16 up to 256 and
-// of 32 above; nmf_fused32.hip: Kp = 32, and 64 / 128 / 256 under NMF_FUSED_VARIANT=3)
+// the two kernel families behind launch_fused_step / launch_check (nmf_fused16.hip: 32 <= Kc <= 512, every multiple of 16 up to 256 and
+// of 32 above; nmf_fused32.hip: Kp = 32 / 64 / 128 / 256 under NMF_FUSED_VARIANT=3 only)
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
 // 512 < Kp <= 1024 (a multiple of 128): two waves share 16 owned columns and split K (nmf_pair16.hip)
@@ -64,7 +64,7 @@ bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc)
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
-int        fused16_compute_k(int K);   // the multiple of 16 (of 32 above 256) the 16-column kernel computes on for 32 < K <= 512, else 0
+int        fused16_compute_k(int K);   // the multiple of 16 (>= 32; of 32 above 256) the 16-column kernel computes on for K <= 512, else 0
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
 #ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library

@@ -27,10 +27,10 @@ extern "C" __attribute__((visibility("default"))) const char *nmf_debug_last_ker
 
 namespace nmf {
 
-// which kernel family serves a padded K: the 16-column kernel for K = 64/128/256 (two workgroups per CU) and for
-// 256 < K <= 512 (one), the 32-column v3 for K = 32 or when NMF_FUSED_VARIANT asks for it
+// which kernel family serves a padded K: the 16-column kernel up to 512 (two workgroups per CU up to 256, one above; K <= 32 too since
+// round 4: 98.5 against 91.1 TFLOP/s at 4096 x 65536 x 32), the 32-column v3 only when NMF_FUSED_VARIANT asks for it (K <= 256)
 static bool use_pair(int Kp) { return Kp > 512; }   // two waves per 16 owned columns, K split between them (nmf_pair16.hip)
-static bool use_k16(int Kp) { return !use_pair(Kp) && (Kp > 256 || (Kp >= 64 && fused_variant() == 0)); }
+static bool use_k16(int Kp) { return !use_pair(Kp) && (Kp > 256 || fused_variant() == 0); }
 
 __global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = uint4{0u, 0u, 0u, 0u};

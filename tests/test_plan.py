@@ -45,7 +45,8 @@ import pytest
     ((4096, 65536, 1024), 1, "fused_step_kernel_pair<NBH=8> Mp=4096 Np=65536 Kp=1024 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 600), 1, "fused_step_kernel_pair<NBH=5> Mp=4096 Np=65536 Kp=640 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 2000), 1, "unfused operators (gemm_kernel), Mp=4096 Np=65536 Kp=2016"),
-    ((4096, 65536, 30), 1, "fused_step_kernel_v3<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),
+    ((4096, 65536, 30), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),      # round 4: the 64-column kernel below K = 48 too
+    ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=3"),
 ])
 def test_dispatch_table(ng, shape, batch, want):
     assert ng.plan_describe(*shape, batch) == want
@@ -54,9 +55,6 @@ def test_dispatch_table(ng, shape, batch, want):
 def test_plans_that_are_refused(ng):
     with pytest.raises(ng.NmfError) as e:          # a batch needs the split kernel or the 64-column kernel: not the wave-pair kernel (K > 512)
         ng.plan_describe(1024, 1024, 700, 4)
-    assert e.value.status == 7
-    with pytest.raises(ng.NmfError) as e:          # nor the 32-column kernel
-        ng.plan_describe(4096, 65536, 30, 2, split_kernel=-1)
     assert e.value.status == 7
     # round 4: a batch on the 64-column kernel (blockIdx.y = pair); the splits shrink with the batch
     assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=20> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(8,1)"
