@@ -348,7 +348,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
     // (blockIdx.y = pair: nmf_fused16_impl.h); the 32-column and the wave-pair kernels and the operator path take one pair
     if (batch > 1 && !s->split && !(path == NMF_PATH_FUSED && fused_takes_batch(s->Kp) && s->Mp <= kMaxRowsApplyColsum)) {
-        set_err("batched solvers need the split kernel or the 64-column kernel (32 < K <= 512, M <= 65536)");
+        set_err("batched solvers need the split kernel or the 64-column kernel (K <= 512, M <= 65536)");
         return NMF_ERR_UNSUPPORTED;
     }
     s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
