@@ -110,8 +110,9 @@ typedef struct {
                              * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
                              *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
     int   restart_lanes;    /* update_div_restarts only.  0 = automatic: shapes the split kernel takes (K <= 256 and small enough, see split_kernel)
-                             * run ALL restarts in every launch (the restart index is a grid dimension); other shapes iterate two
-                             * initialisations side by side on their own streams unless one launch already fills the chip.
+                             * and shapes of the 64-column kernel whose lone launch leaves CUs idle (K <= 512, N < 32768) run ALL restarts in
+                             * every launch (the restart index is a grid dimension); other shapes iterate two initialisations side by side on
+                             * their own streams unless one launch already fills the chip.
                              * n > 0: n stream lanes (1 = one restart after the other), never the batched grid */
     int   split_kernel;     /* which fused kernel family: 0 = automatic; 1 = the split kernel (four waves per 16 owned columns,
                              * normalisers summed in-stream, two to four launches per iteration: problems that do not fill

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     double kl = 0.0, dabs = 0.0, xabs = 0.0;
     // FusedArgs::vsum_part: wave w of q-block b sums row 4 b + w of H over this split's columns
     const bool vsum_on = WSTEP && PARTIAL && a.vsum_part != nullptr;
-    const int vrow_raw = qblk * 4 + wave, vrow = vrow_raw < KS ? vrow_raw : KS - 1;   // all KS rows of the image: the padding rows sum to zero
+    // lanes 0 .. 31 sum row 4 b + w over the chunk's 32 columns, lanes 32 .. 63 the row one pass further on (+ 4 x the q-blocks of a split):
+    // a split's workgroups cover 8 Mp / 64 rows at no extra instruction.  All KS rows of the image: the padding rows sum to zero
+    const int vrow_raw = qblk * 4 + wave + (lane >> 5) * (4 * (int)(gridDim.x / (unsigned)nsplit)), vrow = vrow_raw < KS ? vrow_raw : KS - 1;
     float vs_acc = 0.f;
 
     if (c_begin < c_end) {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
         if (vsum_on) {
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) vs_acc += __shfl_down(vs_acc, off, 32);
-            if (lane == 0 && vrow_raw < KS) a.vsum_part[(pair * nsplit + (size_t)split) * KS + vrow_raw] = vs_acc;
+            if ((lane & 31) == 0 && vrow_raw < KS) a.vsum_part[(pair * nsplit + (size_t)split) * KS + vrow_raw] = vs_acc;
         }
     }
     if (CHECK) {

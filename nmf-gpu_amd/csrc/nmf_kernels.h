@@ -47,7 +47,7 @@ struct FusedArgs {
     size_t strideW = 0, strideH = 0;
     int batch = 1;
     const int *active = nullptr;  // optional [batch] flags: 0 = leave this pair untouched (it has converged)
-    float *vsum_part = nullptr;   // optional, W-step with partial slabs on the 16-column kernel (fused_streams_vsum()): nsplit x Kp
+    float *vsum_part = nullptr;   // optional, W-step with partial slabs on the 16-column kernel (fused_streams_vsum(): Kp <= Mp / 8): nsplit x Kp
                               //    floats receiving, per split, the row sums of the streamed factor H over that split's columns
                               //    -- the W-step normaliser (sum_rows, cuda/nmf.cu:164) read off the LDS image as it streams by
 };

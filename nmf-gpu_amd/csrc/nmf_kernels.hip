@@ -64,8 +64,8 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
     return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, Kc, part, stream, batch, strideW, strideH) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
 }
 
-// one row of H per wave and workgroup: the Mp/64 workgroups of a split must cover all Kp rows
-bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 4 >= (size_t)Kp; }
+// two rows of H per wave and workgroup (one per half-wave): the Mp/64 workgroups of a split must cover all Kp rows
+bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 8 >= (size_t)Kp; }
 bool fused_takes_batch(int Kp) { return use_k16(Kp); }
 int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
 // K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 512 -- the 16-column kernel has an

@@ -752,13 +752,16 @@ def test_division_operands_outside_the_guard_range(ng, oracle, case):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("M,N,K,nsplit_w", [(1024, 700, 64, 3), (2048, 333, 128, 2), (8192, 96, 512, 2), (1000, 260, 64, 4)])
+@pytest.mark.parametrize("M,N,K,nsplit_w", [(1024, 700, 64, 3), (2048, 333, 128, 2), (8192, 96, 512, 2), (1000, 260, 64, 4), (2048, 300, 256, 2), (1024, 260, 120, 3),
+                                            (512, 200, 100, 1)])
 def test_w_step_row_sums_from_the_streaming_kernel(ng, oracle, M, N, K, nsplit_w):
-    """Shapes tall enough (Mp/64 * 4 >= Kp) for the slab-writing W-step to deliver rowsum(H) per split as a side
-    product of streaming H (FusedArgs::vsum_part) instead of the two row-sum kernels: ragged N (zero-padded columns
-    must not contribute), several slabs, all three NB ranges; against the oracle's sum_rows path."""
+    """Shapes tall enough (Mp/64 * 8 >= Kp: two rows of H per wave, one per half-wave, since round 4) for the slab-writing W-step to
+    deliver rowsum(H) per split as a side product of streaming H (FusedArgs::vsum_part) instead of the two row-sum kernels: ragged
+    N (zero-padded columns must not contribute), several slabs, K = M / 8 exactly (the upper half-waves' rows all in use), a K
+    between the powers of two; and one shape beyond the limit (512 x 200 x 100: K > M / 8, the row-sum kernels); against the oracle's
+    sum_rows path."""
     X, W, H = oracle.gen_problem(M, N, K, seed=31)
-    s = ng.Solver(M, N, K, path=ng.PATH_FUSED, nsplit_w=nsplit_w, use_graph=False)
+    s = ng.Solver(M, N, K, path=ng.PATH_FUSED, nsplit_w=nsplit_w, use_graph=False, split_kernel=-1)
     s.upload(W, H, X)
     s.update_w()
     W1, H1 = s.download()
