@@ -15,9 +15,9 @@ NMF_K16_ALL(NMF_K16_EXTERN)
 int fused16_compute_k(int K) {
     if (K > 512 || K < 1) return 0;
     const int kc = K <= 256 ? ((K + 15) & ~15) : ((K + 31) & ~31);
-    return kc < 32 ? 32 : kc;
+    return kc;
 }
-static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 32 && Kc <= 512 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
+static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 16 && Kc <= 512 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
 
 // C(Mp x Np) = A(Mp x Kp) * B(Kp x Np), all contiguous column-major; Mp % 32 == 0, Np % 16 == 0, Kp a multiple of 32 in [64, 512]
 // (the kernel stages whole 32-column pieces of A: no padding inside a caller's matrix to read instead)

@@ -1,4 +1,4 @@
-// nmf_fused16_impl.h -- the production fused half-step of update_div (cuda/nmf.cu:118-176) for 48 <= K <= 512:
+// nmf_fused16_impl.h -- the production fused half-step of update_div (cuda/nmf.cu:118-176) for K <= 512:
 // 16 owned columns per wave on v_mfma_f32_16x16x4_f32, and the KL check built from the same code.
 // Included by nmf_fused16.hip (dispatch) and nmf_fused16_inst.hip (the instantiations, compiled in groups).
 #pragma once
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
     // next to MFMAs whose hazards it must see) cost the untrimmed kernels 0.2 .. 1 % and the split kernel 9 .. 12 %
     // (profiles/r04_trim_ab.log, r04_small_levers.log).
     static_assert(TRIM == 0 || ((TRIM == 2 || TRIM == 3) && RR >= 4 && KT <= 16 && !CHECK && !GEMM), "the trimmed chains exist for the K <= 256 half-steps");
+    static_assert(KT > 1 || TRIM < 3, "K = 16 has four steps: its chain may end two early, not three");
     constexpr bool IL = TRIM > 0;
     constexpr int N1R = N1 - TRIM;      // product-1 steps that are issued
     const int rl = k16_rem_lane<RR, IL>(kq);   // lane part of the k index in the remainder block
@@ -239,14 +240,15 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     // which is the second half exactly where KT is even)
                     constexpr int NLD = GEMM ? NST : NST + 2;   // the check also fetches the next X tile (first: it is used first)
                     constexpr int GL = (E1 / 2) / (NLD + 1) > 0 ? (E1 / 2) / (NLD + 1) : 1;
-                    constexpr int ES = E1 - 8 * NST;
+                    constexpr int ES = KT == 1 ? 4 : E1 - 8 * NST;   // K = 16: eight steps in all, the loads sit in the first four,
+                    constexpr int SS = KT == 1 ? 1 : 2;              //         so a ds_write behind each MFMA of the last four
                     if (e >= GL && e % GL == 0 && e / GL - 1 < NLD) {
                         const int l = e / GL - 1;
                         if (GEMM) stage_load_one(l); else if (l < 2) x_load_one(l); else stage_load_one(l - 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (e >= ES && (e - ES) % 2 == 0 && (e - ES) / 2 < 4 * NST) {
-                        stage_store_one(vn, (e - ES) / 2);
+                    if (e >= ES && (e - ES) % SS == 0 && (e - ES) / SS < 4 * NST) {
+                        stage_store_one(vn, (e - ES) / SS);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
@@ -414,8 +416,8 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
             }                                                                                                                         \
             return hipGetLastError();                                                                                                 \
         }
-        if (a.p1_trim == 3) NMF_LAUNCH_K16_TRIM(3)
-        if (a.p1_trim == 2) NMF_LAUNCH_K16_TRIM(2)
+        if constexpr (KT > 1) { if (a.p1_trim == 3) NMF_LAUNCH_K16_TRIM(3) }
+        if (a.p1_trim >= 2) NMF_LAUNCH_K16_TRIM(2)
 #undef NMF_LAUNCH_K16_TRIM
     }
     if (fast) {
@@ -463,10 +465,10 @@ hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int
     return hipGetLastError();
 }
 
-// Every KT with a kernel: all multiples of 16 from K = 48 to 256, all multiples of 32 above, in the four groups
+// Every KT with a kernel: all multiples of 16 from K = 16 to 256, all multiples of 32 above, in the four groups
 // nmf_fused16_inst.hip is compiled in (balanced by code size).  X(KT) is applied to each.
 #define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32)
-#define NMF_K16_GROUP1(X) X(11) X(12) X(13) X(14) X(30)
+#define NMF_K16_GROUP1(X) X(1) X(11) X(12) X(13) X(14) X(30)
 #define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28)
 #define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26)
 #define NMF_K16_ALL(X) NMF_K16_GROUP0(X) NMF_K16_GROUP1(X) NMF_K16_GROUP2(X) NMF_K16_GROUP3(X)

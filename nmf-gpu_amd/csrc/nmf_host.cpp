@@ -279,7 +279,9 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     // K <= 32: against the 32-column kernel the split kernel stayed ahead through 2^25; against the 64-column kernel's K = 32
     // instantiation, which serves K <= 32 since round 4, it leads by 16 % at 2^23, ties at 2^24 and trails by 2-10 % beyond
     // (profiles/r04_crossover_k32.log)
-    const int lg = kc <= 112 ? 24 : (kc <= 224 ? 23 : 22);
+    // K <= 16, where the 64-column kernel has its K = 16 instantiation and the split kernel computes on 32: level at 2^23 (1.00-1.23),
+    // 5-18 % behind at 2^24 (profiles/r04_crossover_k16.log)
+    const int lg = K <= 16 ? 23 : (kc <= 112 ? 24 : (kc <= 224 ? 23 : 22));
     return (size_t)M * (size_t)N <= ((size_t)1 << lg);
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
@@ -341,9 +343,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // product 1 of the 64-column kernel steps through K four at a time: where the last two or three steps hold zero padding only
     // (K = 100 on the K = 112 kernel; K = 200 on K = 208) a variant whose chain ends that many steps early runs (nmf_fused16_impl.h: TRIM)
     s->p1_trim = 0;
-    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 32 && s->Kc <= 256 && !getenv("NMF_NO_P1_TRIM")) {
+    if (path == NMF_PATH_FUSED && !s->split && s->Kc >= 16 && s->Kc <= 256 && !getenv("NMF_NO_P1_TRIM")) {
         const int zero_steps = (s->Kc - ((K + 3) & ~3)) / 4;
         s->p1_trim = zero_steps >= 3 ? 3 : (zero_steps == 2 ? 2 : 0);
+        if (s->Kc == 16 && s->p1_trim > 2) s->p1_trim = 2;   // four steps in all: two of them stay
     }
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
     // (blockIdx.y = pair: nmf_fused16_impl.h); the 32-column and the wave-pair kernels and the operator path take one pair

@@ -61,11 +61,12 @@ def test_split_kernel_200_iterations_vs_oracle(ng, oracle, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,split_kernel", [(512, 768, K, 1) for K in (48, 96, 100, 160, 192, 200, 224)] +
-                         [(1024, 4096, 48, -1)] + [(1024, 2048, K, -1) for K in (100, 192, 224)])
+                         [(1024, 4096, 48, -1), (1024, 4096, 16, -1), (768, 4096, 7, -1)] + [(1024, 2048, K, -1) for K in (100, 192, 224)])
 def test_k_between_the_powers_of_two_200_iterations_vs_oracle(ng, oracle, M, N, K, split_kernel):
     """The K values of round-3 VERDICT item 1 (padded to 128 / 256 until round 3; now computed on the next multiple of 16 in factors
     padded to 32 like the reference's, cuda/matrix.cuh:7): 200 iterations on one small shape through the split kernel (every K) and
-    one larger shape through the 64-column kernel (K = 48; 100: a TRIM = 3 variant; 192; 224), hipGraph replay, against the oracle.
+    one larger shape through the 64-column kernel (K = 48; 100: a TRIM = 3 variant; 192; 224; and K = 16, 7 on the K = 16
+    instantiation, 7 on its TRIM = 2 variant), hipGraph replay, against the oracle.
     Bound 1e-5 (north_star gate 1e-4).  Every instantiation's half-steps: tests/test_gpu_instantiations.py."""
     X, W, H = oracle.gen_problem(M, N, K, seed=K)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)

@@ -47,6 +47,13 @@ import pytest
     ((4096, 65536, 2000), 1, "unfused operators (gemm_kernel), Mp=4096 Np=65536 Kp=2016"),
     ((4096, 65536, 30), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),      # round 4: the 64-column kernel below K = 48 too
     ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=3"),
+    ((4096, 65536, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),      # K <= 16: half the MFMAs of KT = 2
+    ((4096, 65536, 10), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),
+    ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(8,8)"),          # K <= 16: the split kernel's lead ends at 2^23 elements
+    ((4096, 2048, 16), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=2048 Kp=32 splits(h,w)=(2,1) batch=1"),
+    ((4096, 4096, 20), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=4096 Kp=32 splits(h,w)=(1,1) batch=1"),
+    ((4096, 65536, 8), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=2"),
+    ((4096, 65536, 3), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=2"),
 ])
 def test_dispatch_table(ng, shape, batch, want):
     assert ng.plan_describe(*shape, batch) == want
