@@ -221,13 +221,24 @@ void release_stream(hipStream_t st) {
 // launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
 constexpr int kMaxRowsApplyColsum = 65536;
 
-static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch = 1) {
-    // workgroups per split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU),
+// workgroups of the 64-column kernel a CU holds at once, by the registers and the LDS of its instantiations (profiles/r04_kernel_resources.md:
+// K = 16: 90 registers; K <= 64: <= 120; K <= 128: <= 168 and 44 KiB; K <= 256: two by __launch_bounds__; above: one)
+static int k16_resident(int kc) { return kc <= 64 ? 4 : (kc <= 128 ? 3 : (kc <= 256 ? 2 : 1)); }
+
+static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch = 1, int resident = 2) {
+    // workgroups per split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU) -- or, on long reductions, for
+    // one full round of the chip at the kernel's occupancy (256 CUs x `resident` workgroups: the smaller K leave registers for three or
+    // four, and a W-step of 64 row blocks that stops at 512 workgroups ran 2-15 % behind the H-step's 1024 at K <= 128:
+    // 4096 x 65536, K = 16 / 64 / 100 / 128 +4 / +1.2 / +1.2 / +0.7 % per iteration, profiles/r04_nsplit_by_occupancy.log);
     // keep >= 2 chunks of 32 per split.  A launch that carries `batch` pairs (restarts) hands out batch times the workgroups:
     // the split shrinks with it (fewer slabs, shorter apply), as on the split kernel (pick_split).
     const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
     if (nq >= 256) return 1;
     int ns = (int)((512 + nq - 1) / nq);
+    if (resident > 2) {   // the fuller round pays while a workgroup keeps a long loop (>= 96 chunks); at 32-85 it tied or lost 1-4 % to the extra slabs
+        const int ns_full = (int)((256L * resident + nq - 1) / nq);
+        if ((p_extent / 32) / ns_full >= 96) ns = ns_full;
+    }
     const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
     if (ns > max_ns) ns = max_ns;
     if (ns > 64) ns = 64;
@@ -378,8 +389,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         const int qg = fused_cols_per_group(s->Kp);
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call: a restart gets the same splits wherever it runs
         s->split_batch = sb;
-        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb);
-        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb);
+        const char *rese = getenv("NMF_NSPLIT_RESIDENT");   // A/B: 2 = the splits of rounds 1-3 (512 workgroups whatever the K)
+        const int res = rese ? atoi(rese) : ((s->Kp <= 512 && !getenv("NMF_FUSED_VARIANT")) ? k16_resident(s->Kc) : 2);
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
         s->chk_groups = check_num_groups(s->Np, s->Kp);

@@ -24,19 +24,19 @@ import pytest
     ((512, 3445, 30), 16, "split_step_kernel_k16<KT=2> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,1) batch=16"),
     # K between the powers of two: padded to 32 in HBM like the reference (cuda/matrix.cuh:7), computed on the next multiple of 16
     # (of 32 above 256) -- round 3 padded all of these to 128 / 256
-    ((4096, 65536, 96), 1, "fused_step_kernel_k16<KT=6> Mp=4096 Np=65536 Kp=96 nsplit(h,w)=(1,8)"),
-    ((4096, 65536, 100), 1, "fused_step_kernel_k16<KT=7> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,8) p1_trim=3"),
+    ((4096, 65536, 96), 1, "fused_step_kernel_k16<KT=6> Mp=4096 Np=65536 Kp=96 nsplit(h,w)=(1,12)"),
+    ((4096, 65536, 100), 1, "fused_step_kernel_k16<KT=7> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,12) p1_trim=3"),
     ((4096, 65536, 160), 1, "fused_step_kernel_k16<KT=10> Mp=4096 Np=65536 Kp=160 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 192), 1, "fused_step_kernel_k16<KT=12> Mp=4096 Np=65536 Kp=192 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 200), 1, "fused_step_kernel_k16<KT=13> Mp=4096 Np=65536 Kp=224 nsplit(h,w)=(1,8) p1_trim=2"),
-    ((4096, 65536, 48), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 48), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16)"),
     ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=20> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),
-    ((4096, 65536, 37), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=2"),      # product 1 on 40 of 48
-    ((4096, 65536, 36), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=3"),       # product 1 on 36 of 48
+    ((4096, 65536, 37), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=2"),      # product 1 on 40 of 48
+    ((4096, 65536, 36), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=3"),       # product 1 on 36 of 48
     ((4096, 65536, 250), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),            # one zero step only: the full chain
     ((4096, 65536, 244), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8) p1_trim=3"),
-    ((4096, 65536, 50), 1, "fused_step_kernel_k16<KT=4> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,8) p1_trim=3"),       # product 1 on 52 of 64: the last whole block interleaved in the TRIM variants
-    ((4096, 65536, 120), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,8) p1_trim=2"),
+    ((4096, 65536, 50), 1, "fused_step_kernel_k16<KT=4> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=3"),       # product 1 on 52 of 64: the last whole block interleaved in the TRIM variants
+    ((4096, 65536, 120), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,12) p1_trim=2"),
     ((4096, 350, 100), 1, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
     ((4096, 350, 200), 1, "split_step_kernel_k16<KT=13> Mp=4096 Np=384 Kp=224 splits(h,w)=(11,1) batch=1"),
     ((4096, 350, 100), 16, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
@@ -45,15 +45,15 @@ import pytest
     ((4096, 65536, 1024), 1, "fused_step_kernel_pair<NBH=8> Mp=4096 Np=65536 Kp=1024 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 600), 1, "fused_step_kernel_pair<NBH=5> Mp=4096 Np=65536 Kp=640 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 2000), 1, "unfused operators (gemm_kernel), Mp=4096 Np=65536 Kp=2016"),
-    ((4096, 65536, 30), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),      # round 4: the 64-column kernel below K = 48 too
-    ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=3"),
-    ((4096, 65536, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),      # K <= 16: half the MFMAs of KT = 2
-    ((4096, 65536, 10), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 30), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),      # round 4: the 64-column kernel below K = 48 too
+    ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=3"),
+    ((4096, 65536, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),      # K <= 16: half the MFMAs of KT = 2
+    ((4096, 65536, 10), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),
     ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(8,8)"),          # K <= 16: the split kernel's lead ends at 2^23 elements
     ((4096, 2048, 16), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=2048 Kp=32 splits(h,w)=(2,1) batch=1"),
     ((4096, 4096, 20), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=4096 Kp=32 splits(h,w)=(1,1) batch=1"),
-    ((4096, 65536, 8), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=2"),
-    ((4096, 65536, 3), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,8) p1_trim=2"),
+    ((4096, 65536, 8), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=2"),
+    ((4096, 65536, 3), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=2"),
 ])
 def test_dispatch_table(ng, shape, batch, want):
     assert ng.plan_describe(*shape, batch) == want
