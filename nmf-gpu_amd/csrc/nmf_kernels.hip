@@ -163,20 +163,46 @@ __global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict_
     } else n = nrm[k];
     const size_t count = (size_t)Mp * Kp, col = (size_t)k * Mp;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < Mp; i += 1024) {
-        // slabs summed in the fixed order 0, 1, 2, ... with four loads in flight: 128-256 workgroups have nothing else to hide an
-        // L2 round trip behind, and eight of them in a row were the whole 12.7 us of this kernel
-        const float *__restrict__ p = P + col + i;
-        float s = p[0];
-        int sp = 1;
-        for (; sp + 4 <= nsplit; sp += 4) {
-            const float a0 = p[(size_t)sp * count], a1 = p[(size_t)(sp + 1) * count], a2 = p[(size_t)(sp + 2) * count], a3 = p[(size_t)(sp + 3) * count];
-            s += a0; s += a1; s += a2; s += a3;
+    // 32-256 workgroups have nothing to hide an L2 round trip behind but their own loads: four rows per thread at a time, the slabs of
+    // all four fetched eight deep before the first add (worth 2-3 us per iteration: profiles/r04_apply_w_colsum_ab.log).  The sums keep
+    // their fixed order: slabs 0, 1, 2, ... per element, rows t, t + 1024, ... per thread.
+    constexpr int R = 4, S = 8;
+    for (int i0 = threadIdx.x; i0 < Mp; i0 += R * 1024) {
+        float s[R], wv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = i0 + r * 1024;
+            s[r] = i < Mp ? P[col + i] : 0.f;
+            wv[r] = i < Mp ? W[col + i] : 0.f;
         }
-        for (; sp < nsplit; ++sp) s += p[(size_t)sp * count];
-        const float w = __fmul_rn(W[col + i], s / n);   // _rn: the product that is stored is the one that is summed (no fma contraction)
-        W[col + i] = w;
-        acc = __fadd_rn(acc, w);
+        int sp = 1;
+        for (; sp + S <= nsplit; sp += S) {
+            float a[R][S];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < S; ++e) a[r][e] = (i0 + r * 1024 < Mp) ? P[(size_t)(sp + e) * count + col + i0 + r * 1024] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < S; ++e) s[r] += a[r][e];
+        }
+        for (; sp < nsplit; ++sp) {
+            float a[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = (i0 + r * 1024 < Mp) ? P[(size_t)sp * count + col + i0 + r * 1024] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] += a[r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = i0 + r * 1024;
+            if (i < Mp) {
+                const float w = __fmul_rn(wv[r], s[r] / n);   // _rn: the product that is stored is the one that is summed (no fma contraction)
+                W[col + i] = w;
+                acc = __fadd_rn(acc, w);
+            }
+        }
     }
     const float tot = column_total_1024(acc);
     if (threadIdx.x == 0) norm_out[k] = clamp_eps(tot);
