@@ -169,31 +169,28 @@ __global__ __launch_bounds__(1024) void apply_w_colsum_kernel(float *__restrict_
     constexpr int R = 4, S = 8;
     for (int i0 = threadIdx.x; i0 < Mp; i0 += R * 1024) {
         float s[R], wv[R];
+        const float *__restrict__ p[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = i0 + r * 1024;
-            s[r] = i < Mp ? P[col + i] : 0.f;
-            wv[r] = i < Mp ? W[col + i] : 0.f;
+            p[r] = P + col + (i < Mp ? i : i0);   // rows past the end re-read row i0 and are dropped below
+            wv[r] = W[col + (i < Mp ? i : i0)];
+            s[r] = 0.f;
         }
-        int sp = 1;
-        for (; sp + S <= nsplit; sp += S) {
-            float a[R][S];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int e = 0; e < S; ++e) a[r][e] = (i0 + r * 1024 < Mp) ? P[(size_t)(sp + e) * count + col + i0 + r * 1024] : 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int e = 0; e < S; ++e) s[r] += a[r][e];
+        int sp = 0;
+        // slab 0 starts the sum (assigned, not added to zero: the bits of the one-slab-at-a-time loop this replaces)
+#define NMF_APPLY_BATCH(B)                                                                        \
+        for (; sp + (B) <= nsplit; sp += (B)) {                                                   \
+            float a[R][B];                                                                        \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                         \
+                _Pragma("unroll") for (int e = 0; e < (B); ++e) a[r][e] = p[r][(size_t)(sp + e) * count]; \
+            _Pragma("unroll") for (int r = 0; r < R; ++r)                                         \
+                _Pragma("unroll") for (int e = 0; e < (B); ++e) s[r] = (sp == 0 && e == 0) ? a[r][0] : s[r] + a[r][e]; \
         }
-        for (; sp < nsplit; ++sp) {
-            float a[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[r] = (i0 + r * 1024 < Mp) ? P[(size_t)sp * count + col + i0 + r * 1024] : 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) s[r] += a[r];
-        }
+        NMF_APPLY_BATCH(S)
+        NMF_APPLY_BATCH(4)
+        NMF_APPLY_BATCH(1)
+#undef NMF_APPLY_BATCH
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = i0 + r * 1024;
