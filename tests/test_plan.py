@@ -49,6 +49,8 @@ import pytest
     ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=3"),
     ((4096, 65536, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),      # K <= 16: half the MFMAs of KT = 2
     ((4096, 65536, 10), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),
+    ((4096, 32768, 128), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=32768 Kp=128 nsplit(h,w)=(1,8)"),     # 1024 chunks / 12 < 96 per workgroup: the 512-workgroup rule stays
+    ((65536, 4096, 64), 1, "fused_step_kernel_k16<KT=4> Mp=65536 Np=4096 Kp=64 nsplit(h,w)=(16,1)"),      # the H-step's split follows the same rule
     ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(8,8)"),          # K <= 16: the split kernel's lead ends at 2^23 elements
     ((4096, 2048, 16), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=2048 Kp=32 splits(h,w)=(2,1) batch=1"),
     ((4096, 4096, 20), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=4096 Kp=32 splits(h,w)=(1,1) batch=1"),
