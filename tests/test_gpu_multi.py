@@ -299,11 +299,12 @@ def test_concurrent_ranks_each_with_an_rccl_communicator_capture_and_replay_thei
         assert oracle.relF(Wt, Wr) < 1e-5 and oracle.relF(Ht, Hr) < 1e-5 and np.allclose(rt["kl"], klr, rtol=2e-5), (M, N, K)
 
 
-@pytest.mark.parametrize("K,G", [(160, 2), (100, 3)])
+@pytest.mark.parametrize("K,G", [(160, 2), (100, 3), (12, 2)])
 def test_sharded_64_column_kernel_at_a_rank_between_the_powers_of_two(ng, oracle, K, G):
     """The in-library driver with emulated shards where every rank runs the 64-column kernel (split_kernel = -1) at a K that is not a
     power of two: K = 160 (KT = 10, factors padded to 160) and K = 100 (KT = 7 with three steps of product 1 trimmed, factors padded
-    to 128: the all-reduce operand and the slabs carry zero padding rows).  60 iterations against the oracle, replicas identical."""
+    to 128: the all-reduce operand and the slabs carry zero padding rows) -- and K = 12 on the K = 16 instantiation (factors padded to
+    32: half of every slab is padding).  60 iterations against the oracle, replicas identical."""
     M, N = 512, 2048
     X, W, H = oracle.gen_problem(M, N, K, seed=41)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)

@@ -241,7 +241,7 @@ def test_batched_restarts_with_the_batch_sized_split_match_the_oracle_per_restar
 
 
 @pytest.mark.parametrize("M,N,K,R,thresh,kw", [(2048, 2560, 256, 3, 0.0, {}), (1024, 2048, 320, 3, 0.0, {}), (4096, 1500, 100, 3, 0.0, {"split_kernel": -1}),
-                                               (2048, 1024, 96, 6, 2e-3, {"split_kernel": -1})])
+                                               (2048, 1024, 96, 6, 2e-3, {"split_kernel": -1}), (1024, 1536, 12, 4, 0.0, {"split_kernel": -1})])
 def test_batched_restarts_on_the_64_column_kernel_match_the_oracle_per_restart(ng, oracle, M, N, K, R, thresh, kw):
     """Round-3 VERDICT next 5 (paper section 3.2): shapes the split kernel does not take -- K > 256, or above its crossover -- but
     whose lone launch does not fill the chip run all restarts in every launch of the 64-column kernel too (blockIdx.y = restart:
