@@ -11,11 +11,10 @@ namespace nmf {
 NMF_K16_ALL(NMF_K16_EXTERN)
 #undef NMF_K16_EXTERN
 
-// the K the 16-column kernel computes on for a logical K: the next instantiated multiple of 16 (of 32 above 256), 0 = none
+// the K the 16-column kernel computes on for a logical K: the next multiple of 16 (every one up to 512 is instantiated), 0 = none
 int fused16_compute_k(int K) {
     if (K > 512 || K < 1) return 0;
-    const int kc = K <= 256 ? ((K + 15) & ~15) : ((K + 31) & ~31);
-    return kc;
+    return (K + 15) & ~15;
 }
 static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 16 && Kc <= 512 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
 

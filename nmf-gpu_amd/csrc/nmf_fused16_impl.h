@@ -11,7 +11,7 @@ namespace nmf {
 // accumulator (4 KT registers) and the K B-operands of product 1 (4 KT registers) fit the register file.
 // The template parameter is KT = K / 16, the number of 16-row accumulator tiles: the reference pads K to a multiple of 32 and
 // nothing coarser (cuda/matrix.cuh:7, cuda/matrix.cu:88-95), and NMF ranks are rarely powers of two, so the kernel is
-// instantiated for every multiple of 16 up to 256 and every multiple of 32 up to 512.  The factors in HBM and the LDS image
+// instantiated for every multiple of 16 up to 512.  The factors in HBM and the LDS image
 // are padded to KS = 32 ceil(KT / 2) columns (= FusedArgs::Kp; zeros beyond K); the MFMAs cover K = 16 KT (= FusedArgs::Kc).
 // Lane maps of the 16x16x4 form (lane l: j = l & 15, kq = l >> 4):
 //     A operand = A[row j][k kq],  B operand = B[k kq][col j],  result reg r = D[4 kq + r][j]
@@ -465,12 +465,12 @@ hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int
     return hipGetLastError();
 }
 
-// Every KT with a kernel: all multiples of 16 from K = 16 to 256, all multiples of 32 above, in the four groups
+// Every KT with a kernel: all multiples of 16 from K = 16 to 512, in the four groups
 // nmf_fused16_inst.hip is compiled in (balanced by code size).  X(KT) is applied to each.
-#define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32)
-#define NMF_K16_GROUP1(X) X(1) X(11) X(12) X(13) X(14) X(30)
-#define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28)
-#define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26)
+#define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32) X(17)
+#define NMF_K16_GROUP1(X) X(1) X(11) X(12) X(13) X(14) X(30) X(19) X(31)
+#define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28) X(21) X(29)
+#define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26) X(23) X(25) X(27)
 #define NMF_K16_ALL(X) NMF_K16_GROUP0(X) NMF_K16_GROUP1(X) NMF_K16_GROUP2(X) NMF_K16_GROUP3(X)
 
 }  // namespace nmf

@@ -343,7 +343,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
         if (!fused_pad_k(K)) { set_err("fused path supports K <= %d", kMaxFusedK); return NMF_ERR_UNSUPPORTED; }
-        // K in HBM is padded to 32 (cuda/matrix.cuh:7) and the 16-column kernels compute on the next multiple of 16 (of 32 above 256)
+        // K in HBM is padded to 32 (cuda/matrix.cuh:7) and the 16-column kernels compute on the next multiple of 16
         s->Kp = s->split ? split_pad_k(K) : fused_pad_k(K);
         s->Kc = s->split ? split_compute_k(K) : fused_compute_k(K);
     } else {

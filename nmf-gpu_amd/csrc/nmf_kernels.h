@@ -64,7 +64,7 @@ bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc)
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
-int        fused16_compute_k(int K);   // the multiple of 16 (of 32 above 256) the 16-column kernel computes on for K <= 512, else 0
+int        fused16_compute_k(int K);   // the multiple of 16 the 16-column kernel computes on for K <= 512, else 0
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
 #ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library

@@ -69,7 +69,7 @@ bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 6
 bool fused_takes_batch(int Kp) { return use_k16(Kp); }
 int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
 // K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 512 -- the 16-column kernel has an
-// instantiation for every multiple of 16 up to 256 and of 32 up to 512 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
+// instantiation for every multiple of 16 up to 512 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
 // an A/B switch) only exists for 32 / 64 / 128 / 256.  0 = not supported.
 int fused_pad_k(int K) {
     const int k32 = pad32(K);

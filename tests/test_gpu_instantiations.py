@@ -52,11 +52,11 @@ def recording(ng):
     ng.record_kernels(old)
 
 
-K16_KTS = tuple(range(1, 17)) + tuple(range(18, 33, 2))   # every multiple of 16 from K = 16 to 256, of 32 from 288 to 512
+K16_KTS = tuple(range(1, 33))   # every multiple of 16 from K = 16 to 512
 
 
 def test_every_instantiation_of_the_64_column_kernel(ng, oracle, recording):
-    """fused_step_kernel_k16<KT, WSTEP, PARTIAL, DIV, CHECK, OCC, GEMM, TRIM>: KT = K/16 in 1..16 (OCC = 2) and 18, 20, .. 32 (OCC = 1),
+    """fused_step_kernel_k16<KT, WSTEP, PARTIAL, DIV, CHECK, OCC, GEMM, TRIM>: KT = K/16 in 1..16 (OCC = 2) and 17..32 (OCC = 1),
     both half-steps, in-place and partial-slab epilogues, both quotients, and the CHECK instantiation of every KT.  The odd KT
     (K = 48, 80, ... 240: a remainder block in the k map, a zero-padded half piece in the LDS image) are the round-4 additions, as
     are the TRIM = 2, 3 variants (K <= 256, K % 64 != 0): a caller's K that leaves the last two / three steps of product 1 on zero
@@ -82,10 +82,9 @@ def test_every_instantiation_of_the_64_column_kernel(ng, oracle, recording):
 
 
 def test_a_logical_k_between_two_instantiations_runs_the_next_multiple_of_16(ng, oracle, recording):
-    """K = 100 computes on 112 (KT = 7) in factors padded to 128; K = 200 on 208; K = 33 on 48; K = 270 on 288 (multiples of 32
-    above 256): the reference pads to 32 and nothing coarser (cuda/matrix.cuh:7)."""
+    """K = 100 computes on 112 (KT = 7) in factors padded to 128; K = 200 on 208; K = 33 on 48; K = 270 on 272, 300 on 304, 400 on 400 (factors padded to 288 / 320 / 416): the reference pads to 32 and nothing coarser (cuda/matrix.cuh:7)."""
     seen = set()
-    for K, kt in ((100, 7), (200, 13), (33, 3), (270, 18), (97, 7), (250, 16), (30, 2), (17, 2), (10, 1)):
+    for K, kt in ((100, 7), (200, 13), (33, 3), (270, 17), (300, 19), (400, 25), (97, 7), (250, 16), (30, 2), (17, 2), (10, 1)):
         seen.clear()
         _half_steps(ng, oracle, 160, 208, K, seen, split_kernel=-1)
         assert {a[0] for n, a in seen if n == "fused_step_kernel_k16"} == {str(kt)}, (K, seen)

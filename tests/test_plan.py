@@ -23,14 +23,15 @@ import pytest
     ((1024, 4096, 64), 4, "split_step_kernel_k16<KT=4> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,2) batch=4"),
     ((512, 3445, 30), 16, "split_step_kernel_k16<KT=2> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,1) batch=16"),
     # K between the powers of two: padded to 32 in HBM like the reference (cuda/matrix.cuh:7), computed on the next multiple of 16
-    # (of 32 above 256) -- round 3 padded all of these to 128 / 256
+    # -- round 3 padded all of these to 128 / 256
     ((4096, 65536, 96), 1, "fused_step_kernel_k16<KT=6> Mp=4096 Np=65536 Kp=96 nsplit(h,w)=(1,12)"),
     ((4096, 65536, 100), 1, "fused_step_kernel_k16<KT=7> Mp=4096 Np=65536 Kp=128 nsplit(h,w)=(1,12) p1_trim=3"),
     ((4096, 65536, 160), 1, "fused_step_kernel_k16<KT=10> Mp=4096 Np=65536 Kp=160 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 192), 1, "fused_step_kernel_k16<KT=12> Mp=4096 Np=65536 Kp=192 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 200), 1, "fused_step_kernel_k16<KT=13> Mp=4096 Np=65536 Kp=224 nsplit(h,w)=(1,8) p1_trim=2"),
     ((4096, 65536, 48), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16)"),
-    ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=20> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=19> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),     # end of round 4: every multiple of 16 up to 512
+    ((4096, 65536, 400), 1, "fused_step_kernel_k16<KT=25> Mp=4096 Np=65536 Kp=416 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 37), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=2"),      # product 1 on 40 of 48
     ((4096, 65536, 36), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=3"),       # product 1 on 36 of 48
     ((4096, 65536, 250), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),            # one zero step only: the full chain
@@ -66,7 +67,7 @@ def test_plans_that_are_refused(ng):
         ng.plan_describe(1024, 1024, 700, 4)
     assert e.value.status == 7
     # round 4: a batch on the 64-column kernel (blockIdx.y = pair); the splits shrink with the batch
-    assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=20> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(8,1)"
+    assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=19> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(8,1)"
     assert ng.plan_describe(4096, 4096, 256, 1) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(8,8)"
     assert ng.plan_describe(4096, 4096, 256, 8) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(1,1)"
     with pytest.raises(ng.NmfError):
