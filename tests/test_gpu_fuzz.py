@@ -1,0 +1,84 @@
+"""Random shapes through every kernel family against the CPU oracle: M, N in 1 .. 3000, K in 1 .. 600 with the edges of the
+dispatch tables drawn more often (K = 16 / 17, 256 / 257, 512 / 513 ...), the automatic kernel choice or a family forced where it
+applies, random split overrides, either quotient, graph replay or eager launches; a few iterations each against the oracle's
+update_div (cuda/nmf.cu:118-176), W and H within 5e-6 rel-Frobenius and the KL value (cuda/matrix.cu:592) within 5e-5 (+ 1e-6 of sum(X): cancellation).
+The suite runs 60 cases of seed 0; `python tests/test_gpu_fuzz.py <cases> <seed>` runs more (profiles/r04_fuzz.log: 600)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+EDGE_DIMS = (1, 16, 31, 32, 33, 64, 127, 128, 129, 1024)
+EDGE_K = (1, 3, 8, 15, 16, 17, 30, 32, 33, 48, 100, 255, 256, 257, 272, 300, 400, 496, 512, 513)
+
+
+def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
+    rng = np.random.default_rng(seed)
+    worst, fails, fam = 0.0, [], {}
+    for case in range(n_cases):
+        M = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
+        N = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
+        K = int(rng.integers(1, 601)) if rng.random() < 0.7 else int(rng.choice(EDGE_K))
+        kw = {}
+        r = rng.random()
+        if r < 0.35:
+            kw["split_kernel"] = -1
+        elif r < 0.6 and K <= 256:
+            kw["split_kernel"] = 1
+        if rng.random() < 0.3:
+            kw["nsplit_h"] = int(rng.integers(1, 6))
+        if rng.random() < 0.3:
+            kw["nsplit_w"] = int(rng.integers(1, 6))
+        if rng.random() < 0.2:
+            kw["fast_divide"] = 1
+        iters = int(rng.integers(1, 5))
+        graph = bool(rng.random() < 0.5)
+        X, W, H = oracle.gen_problem(M, N, K, seed=int(rng.integers(0, 1 << 30)))
+        s = ng.Solver(M, N, K, use_graph=graph, **kw)
+        name = s.describe().split("<")[0].split(" ")[0]
+        s.upload(W, H, X)
+        s.iterate(iters)
+        Wg, Hg = s.download()
+        kl, _ = s.check()
+        s.close()
+        Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, iters, 25)
+        eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
+        klr = oracle.kl_div(oracle.clamp(X), oracle.clamp(oracle.sgemm("nn", Wr, Hr)))
+        tol = 2e-5 if kw.get("fast_divide") else 5e-6
+        # KL = sum x log(x / y) - x + y is a difference of terms of size sum(x): where the fit is exact (M = 1 or N = 1: rank one) the value
+        # is ~1e-12 and what the kernel's fp32 evaluation of x log y leaves is up to 3e-7 of sum(x) (measured over 600 cases, it can even
+        # come out negative at an exact fit) -- the bound is relative to both
+        ok = (eW < tol and eH < tol and bool(np.isfinite(Wg).all() and np.isfinite(Hg).all())
+              and abs(kl - klr) <= 5e-5 * abs(klr) + 1e-6 * float(np.asarray(X, dtype=np.float64).sum()))
+        fam[name] = fam.get(name, 0) + 1
+        worst = max(worst, eW, eH)
+        line = f"case {case}: ({M},{N},{K}) x{iters} graph={int(graph)} {kw} [{name}]: relF(W)={eW:.2e} relF(H)={eH:.2e} kl {kl:.6e} vs {klr:.6e}"
+        if not ok:
+            fails.append(line)
+            print("FAIL " + line, flush=True)
+        elif verbose and case % 25 == 0:
+            print(line, flush=True)
+    return fails, worst, fam
+
+
+@pytest.mark.gpu
+def test_random_shapes_through_every_family_match_the_oracle(ng, oracle):
+    fails, worst, fam = run_fuzz(ng, oracle, 60, 0)
+    print(f"fuzz: 60 cases, worst relF {worst:.2e}, kernels {fam}")
+    assert not fails, fails
+    assert len(fam) >= 3, fam      # the draw reaches the 64-column, the split and the wave-pair kernels
+
+
+if __name__ == "__main__":
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import nmf_gpu_amd
+    import oracle as oracle_mod
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    fails, worst, fam = run_fuzz(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
+    print(f"{n} cases (seed {sd}) in {time.time() - t0:.0f} s: {len(fails)} failures, worst relF {worst:.2e}; kernels: {fam}")
+    sys.exit(1 if fails else 0)
