@@ -2,7 +2,8 @@
 dispatch tables drawn more often (K = 16 / 17, 256 / 257, 512 / 513 ...), the automatic kernel choice or a family forced where it
 applies, random split overrides, either quotient, graph replay or eager launches; a few iterations each against the oracle's
 update_div (cuda/nmf.cu:118-176), W and H within 5e-6 rel-Frobenius and the KL value (cuda/matrix.cu:592) within 5e-5 (+ 1e-6 of sum(X): cancellation).
-The suite runs 60 cases of seed 0; `python tests/test_gpu_fuzz.py <cases> <seed>` runs more (profiles/r04_fuzz.log: 600)."""
+The suite runs 60 cases of seed 0 (+ 24 through update_div_restarts and the emulated-shards driver); `python tests/test_gpu_fuzz.py <cases> <seed>
+[multi]` runs more (profiles/r04_fuzz.log: 1000 + 200)."""
 import os
 import sys
 import time
@@ -63,6 +64,64 @@ def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
     return fails, worst, fam
 
 
+def run_fuzz_multi(ng, oracle, n_cases, seed, verbose=False):
+    """the same draw through the two callers above a lone solver: update_div_restarts (R pairs against one X: a batch per launch or
+    stream lanes, paper section 3.2) and the N-sharded driver with emulated shards; each pair / the gathered result against
+    the oracle's sequential update_div"""
+    rng = np.random.default_rng(seed)
+    worst, fails, modes = 0.0, [], {}
+    for case in range(n_cases):
+        M = int(rng.integers(1, 1501)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
+        N = int(rng.integers(8, 1501)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS[1:]))
+        K = int(rng.integers(1, 521)) if rng.random() < 0.7 else int(rng.choice(EDGE_K[:-1]))
+        kw = {}
+        r = rng.random()
+        if r < 0.35:
+            kw["split_kernel"] = -1
+        elif r < 0.6 and K <= 256:
+            kw["split_kernel"] = 1
+        iters = int(rng.integers(2, 7))
+        X, W, H = oracle.gen_problem(M, N, K, seed=int(rng.integers(0, 1 << 30)))
+        if rng.random() < 0.5:
+            R = int(rng.integers(2, 6))
+            mode = f"restarts x{R}" + (" lanes" if rng.random() < 0.3 else "")
+            if mode.endswith("lanes"):
+                kw["restart_lanes"] = 2
+            Ws = [np.asfortranarray(rng.random((M, K), dtype=np.float32)) for _ in range(R)]
+            Hs = [np.asfortranarray(rng.random((K, N), dtype=np.float32)) for _ in range(R)]
+            Wm, Hm = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+            best, kls = ng.update_div_restarts(Wm, Hm, ng.Matrix(X), max_iter=iters, **kw)
+            err = 0.0
+            for i in range(R):
+                wr, hr, _, _ = oracle.update_div(Ws[i], Hs[i], X, 0.0, iters, 25)
+                err = max(err, oracle.relF(Wm[i].mat, wr), oracle.relF(Hm[i].mat, hr))
+            ok = err < 5e-6 and best == int(np.argmin(kls))
+        else:
+            G = int(rng.integers(2, 5))
+            mode = f"shards x{G}"
+            Wm, Hm = ng.Matrix(W.copy(order="F")), ng.Matrix(H.copy(order="F"))
+            res = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=iters, emulate_shards=G, **kw)
+            wr, hr, _, _ = oracle.update_div(W, H, X, 0.0, iters, 25)
+            err = max(oracle.relF(Wm.mat, wr), oracle.relF(Hm.mat, hr))
+            ok = err < 5e-6 and res["n_shards"] == G and res["w_replicas_identical"] == 1 and res["iterations"] == iters
+        modes[mode.split(" ")[0]] = modes.get(mode.split(" ")[0], 0) + 1
+        worst = max(worst, err)
+        line = f"case {case}: ({M},{N},{K}) x{iters} {mode} {kw}: worst relF {err:.2e}"
+        if not ok:
+            fails.append(line)
+            print("FAIL " + line, flush=True)
+        elif verbose and case % 10 == 0:
+            print(line, flush=True)
+    return fails, worst, modes
+
+
+@pytest.mark.gpu
+def test_random_shapes_through_restarts_and_emulated_shards_match_the_oracle(ng, oracle):
+    fails, worst, modes = run_fuzz_multi(ng, oracle, 24, 0)
+    print(f"fuzz (restarts / shards): 24 cases, worst relF {worst:.2e}, {modes}")
+    assert not fails, fails
+
+
 @pytest.mark.gpu
 def test_random_shapes_through_every_family_match_the_oracle(ng, oracle):
     fails, worst, fam = run_fuzz(ng, oracle, 60, 0)
@@ -79,6 +138,9 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    fails, worst, fam = run_fuzz(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
-    print(f"{n} cases (seed {sd}) in {time.time() - t0:.0f} s: {len(fails)} failures, worst relF {worst:.2e}; kernels: {fam}")
+    if len(sys.argv) > 3 and sys.argv[3] == "multi":
+        fails, worst, fam = run_fuzz_multi(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
+    else:
+        fails, worst, fam = run_fuzz(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
+    print(f"{n} cases (seed {sd}) in {time.time() - t0:.0f} s: {len(fails)} failures, worst relF {worst:.2e}; kernels / modes: {fam}")
     sys.exit(1 if fails else 0)
