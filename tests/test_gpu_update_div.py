@@ -314,6 +314,32 @@ def test_cfg3_200_iterations_against_the_oracle(ng, oracle, cfg3_problem):
     assert np.isfinite(Wg).all() and np.isfinite(Hg).all()
 
 
+@pytest.mark.parametrize("K,ns_w", [(16, 21), (128, 16)])
+def test_occupancy_sized_splits_on_a_long_reduction_against_the_oracle(ng, oracle, K, ns_w):
+    """End of round 4: where a workgroup keeps >= 96 chunks, the W-step's reduction is cut for one full round of the chip at the
+    kernel's occupancy (four workgroups per CU at K <= 64, three at K <= 128) instead of for 512 workgroups (nmf_host.cpp: pick_nsplit).
+    50 row blocks x 65536 columns: 21 splits at K = 16 (the K = 16 instantiation), 16 at K = 128 (11 by the old rule).  Ten iterations
+    against the oracle, relF <= 5e-6."""
+    M, N = 3200, 65536
+    X, W, H = oracle.gen_problem(M, N, K, seed=K)
+    s = ng.Solver(M, N, K)
+    assert f"nsplit(h,w)=(1,{ns_w})" in s.describe(), s.describe()
+    s.upload(W, H, X)
+    s.iterate(10)
+    Wg, Hg = s.download()
+    s.close()
+    # the oracle's fast arrangement (long reductions summed in blocks of 512), pinned to the oracle's loop at this shape by one iteration;
+    # the loop itself, 8192 terms per fp32 lane over these 65536 columns, drifts from the GPU by 4.6e-6 / 5.3e-6 in ten iterations (measured:
+    # its own rounding -- the GPU stays within 7e-7 of float64 over such reductions, test_gpu_against_an_fp64_evaluation_over_long_reductions)
+    W1r, H1r, _, _ = oracle.update_div(W, H, X, 0.0, 1, 25)
+    W1f, H1f = oracle.update_div_fast(W, H, X, 1)
+    assert oracle.relF(W1f, W1r) < 5e-6 and oracle.relF(H1f, H1r) < 5e-6
+    Wr, Hr = oracle.update_div_fast(W, H, X, 10)
+    eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
+    print(f"{M}x{N}x{K}, {ns_w} W-step splits, 10 iterations: relF(W) = {eW:.2e}, relF(H) = {eH:.2e}")
+    assert eW < 5e-6 and eH < 5e-6 and np.isfinite(Wg).all() and np.isfinite(Hg).all()
+
+
 @pytest.mark.parametrize("M,N,K,kw", [(96, 65536, 16, {}), (128, 65536, 64, {"split_kernel": -1}), (128, 32768, 64, {"split_kernel": 1})])
 def test_gpu_against_an_fp64_evaluation_over_long_reductions(ng, M, N, K, kw):
     """The GPU against float64 numpy directly (no oracle in between), on shapes whose W-step sums 32768-65536 columns: 20
