@@ -66,4 +66,59 @@ def cfg3_problem(oracle):
     return X, W, H
 
 
+class _Cfg3OracleRun:
+    """The CPU side of the cfg3 x 200 comparison -- 200 iterations of the oracle's fast arrangement, about two minutes on the box's 16 cores --
+    run on a background thread (the C oracle releases the GIL) while the other tests of the module go on, so that the comparison itself only
+    waits for what is not finished yet.  The same four calls of 50 iterations each, in the same order, as the test used to make itself; a
+    cancelled session waits for the call in flight (up to ~30 s)."""
+
+    def __init__(self, oracle, problem):
+        import threading
+        self._oracle, self._problem = oracle, problem
+        self._cv = threading.Condition()
+        self._stages, self._err, self._cancel, self.cpu_s = [], None, False, 0.0
+        self._thread = threading.Thread(target=self._work, name="cfg3-oracle", daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        import time
+        X, Wr, Hr = self._problem
+        try:
+            for _ in range(4):
+                if self._cancel:
+                    return
+                t0 = time.time()
+                Wr, Hr = self._oracle.update_div_fast(Wr, Hr, X, 50)
+                self.cpu_s += time.time() - t0
+                with self._cv:
+                    self._stages.append((Wr, Hr))
+                    self._cv.notify_all()
+        except BaseException as e:      # handed to the waiting test
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+
+    def stage(self, i):
+        """(W, H) of the oracle after 50 (i + 1) iterations; blocks until the thread has got there"""
+        with self._cv:
+            while len(self._stages) <= i and self._err is None:
+                self._cv.wait(timeout=1.0)
+                if not self._thread.is_alive() and len(self._stages) <= i and self._err is None:
+                    raise RuntimeError("the cfg3 oracle thread ended early")
+            if self._err is not None:
+                raise self._err
+            return self._stages[i]
+
+    def stop(self):
+        self._cancel = True
+        self._thread.join()
+
+
+@pytest.fixture(scope="session")
+def cfg3_oracle_200(oracle, cfg3_problem):
+    run = _Cfg3OracleRun(oracle, cfg3_problem)
+    yield run
+    run.stop()
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
