@@ -225,25 +225,48 @@ constexpr int kMaxRowsApplyColsum = 65536;
 // K = 16: 90 registers; K <= 64: <= 120; K <= 128: <= 168 and 44 KiB; K <= 256: two by __launch_bounds__; above: one)
 static int k16_resident(int kc) { return kc <= 64 ? 4 : (kc <= 128 ? 3 : (kc <= 256 ? 2 : 1)); }
 
-static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch = 1, int resident = 2) {
-    // workgroups per split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU) -- or, on long reductions, for
-    // one full round of the chip at the kernel's occupancy (256 CUs x `resident` workgroups: the smaller K leave registers for three or
-    // four, and a W-step of 64 row blocks that stops at 512 workgroups ran 2-15 % behind the H-step's 1024 at K <= 128:
-    // 4096 x 65536, K = 16 / 64 / 100 / 128 +4 / +1.2 / +1.2 / +0.7 % per iteration, profiles/r04_nsplit_by_occupancy.log);
-    // keep >= 2 chunks of 32 per split.  A launch that carries `batch` pairs (restarts) hands out batch times the workgroups:
-    // the split shrinks with it (fewer slabs, shorter apply), as on the split kernel (pick_split).
+// The rule of rounds 1-3 (and of the kernels without an occupancy table: the wave-pair and the 32-column kernels): workgroups per
+// split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU), keep >= 2 chunks of 32 per split.
+static int pick_nsplit_512(int q_extent, int p_extent, int q_per_group, int batch) {
     const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
     if (nq >= 256) return 1;
     int ns = (int)((512 + nq - 1) / nq);
-    if (resident > 2) {   // the fuller round pays while a workgroup keeps a long loop (>= 96 chunks); at 32-85 it tied or lost 1-4 % to the extra slabs
-        const int ns_full = (int)((256L * resident + nq - 1) / nq);
-        if ((p_extent / 32) / ns_full >= 96) ns = ns_full;
-    }
     const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
     if (ns > max_ns) ns = max_ns;
     if (ns > 64) ns = 64;
     if (ns < 1) ns = 1;
     return ns;
+}
+
+// How many ways the 64-column kernel cuts a half-step's reduction (each cut = one more workgroup per 64 owned columns and one more slab
+// for the apply launch).  A small model of the launch, fitted to same-box sweeps (profiles/r04_nsplit_by_occupancy.log,
+// r04_nsplit_model.log), picks the cheapest count:
+//   * balance: nq * ns workgroups over 256 CUs -- ceil(wgs / 256) * 256 / wgs (313 row blocks unsplit keep half the chip waiting for
+//     the CUs that got two: 0.519 ms against 0.315 with four cuts at 20000 x 4096 x 128);
+//   * occupancy: a CU holding r = min(resident, ceil(wgs / 256)) workgroups runs at KT / (KT + a_r), a = 1.0 / 0.2 / 0.08 / 0 for r = 1 / 2 /
+//     3 / >= 4 -- one wave per SIMD cannot keep the MFMA pipe fed, and the less so the shorter the chains (K = 16: 0.104 -> 0.056 ms for the
+//     H-step of 4096 x 16384 from one to four workgroups per CU; K = 256: 0.504 -> 0.485);
+//   * fixed work per workgroup: prologue + epilogue ~ two chunks of 32, so 1 + 2 ns / chunks;
+//   * slabs: 0.4 % + 0.2 % per cut for writing them and for the apply launch that sums them.
+// A launch that carries `batch` pairs (restarts) hands out batch times the workgroups and is planned as such -- with the batch of the
+// whole update_div_restarts call, so that a restart gets the same cuts, hence the same bits, wherever it runs.
+static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch, int resident, int kt) {
+    if (resident < 1 || kt < 1) return pick_nsplit_512(q_extent, p_extent, q_per_group, batch);
+    const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
+    const int chunks = p_extent / 32 > 0 ? p_extent / 32 : 1;
+    int max_ns = chunks / 2 > 0 ? chunks / 2 : 1;
+    if (max_ns > 64) max_ns = 64;
+    int best = 1;
+    double best_cost = 0.0;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+        const long wgs = nq * ns, per_cu = (wgs + 255) / 256;
+        const double balance = (double)(per_cu * 256) / (double)wgs;
+        const long r = per_cu < resident ? per_cu : resident;
+        const double a = r <= 1 ? 1.0 : (r == 2 ? 0.2 : (r == 3 ? 0.08 : 0.0));
+        const double cost = balance * ((kt + a) / kt) * (1.0 + 2.0 * ns / chunks) * (ns > 1 ? 1.004 + 0.002 * ns : 1.0);
+        if (ns == 1 || cost < best_cost - 1e-12) { best = ns; best_cost = cost; }
+    }
+    return best;
 }
 
 static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from = nullptr, int batch = 1, int split_batch = 0);
@@ -274,26 +297,39 @@ static int create_batched(nmf_solver **out, int M, int N, int K, int batch, cons
 // Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
 // launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
 // kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1, int wg_per_cu = 1);
+// how far a lone problem's split-kernel launch is from filling the chip evenly: CUs idle (fewer workgroups than CUs) or a part of
+// them running a second round (more), as a factor on the launch's time
+static double split_kernel_balance(int q, int p, int wg_per_cu) {
+    const int qv = (q + 31) & ~31, tasks = qv / 16;
+    const long wgs = (long)tasks * pick_split(qv, (p + 127) & ~127, 128, 1, wg_per_cu);
+    return wgs <= 256 ? 256.0 / (double)wgs : (double)(((wgs + 255) / 256) * 256) / (double)wgs;
+}
 static int split_pad_k(int K) { return K <= 256 ? pad32(K) : 0; }   // K in HBM: padded to 32 like the reference; the kernel computes on split_compute_k(K)
 static bool want_split(int M, int N, int K, const nmf_opts &o) {
     const int kp = split_pad_k(K);
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
     if (((size_t)M + 127) * kp >= ((size_t)1 << 30) || ((size_t)N + 127) * kp >= ((size_t)1 << 30)) return false;
     if (o.split_kernel > 0) return true;
-    // measured crossover (tools/crossover.py, iteration time of both families over M x N from 2^22 to 2^26 elements): the split
-    // kernel is 5-26 % ahead up to 2^23 elements at K = 128 and 2^23-2^24 at K = 64 (a tie at 2^24), 3-14 % behind beyond; at
-    // K <= 32 it stays 10-14 % ahead of the 32-column kernel through 2^25; at K = 256 (one LDS image) 5-58 % ahead up to 2^22.
-    // Round 4, the ranks in between (profiles/r04_crossover_mid_k.log): K = 80 .. 112 ahead or level through 2^24 (K = 96: +13 % at
-    // 2^23, +3 % at 2^24, -4 % at 2^25); K = 144 .. 224 ahead through 2^23 (K = 160: +26 / +12 %, then -9 % at 2^24; K = 224: +3 %
-    // at 2^23); K = 256 behind from 2^23 on.
+    // Measured crossover (tools/crossover.py: iteration time of both families).  Rounds 2-4 fitted it three times as the 64-column kernel
+    // gained instantiations; the last fit (profiles/r04_crossover_model_splits.log) is against its model-chosen splits (pick_nsplit):
+    //   K <= 16 (the split kernel computes on 32):  +16 % at 2^22 elements, level at 2^23, behind beyond
+    //   K <= 112:  +8-27 % through 2^23 (K = 32: +11 %, 64: +8 %, 100: level), then level or 5-6 % behind at 2^24
+    //   K <= 128:  +12-23 % at 2^22, level at 2^23
+    //   K <= 256:  ahead through 2^21 only (K = 200: 8-11 % behind at 2^21.8 .. 2^23; K = 256: +47 % at 2^20, +3 % at 2^21, mixed at 2^22)
+    // and, whatever the K, behind by 17-29 % from 2^22 elements on where its own workgroup count does not fit the chip -- 16 owned columns
+    // per workgroup and at most 256 workgroups: 157 or 314 of them (N = 2500, 5000) leave a third of the CUs idle or waiting for a second
+    // round, where the 64-column kernel cuts its reduction to fit (3000 x 5000 x 100: 198 us against 140).
     const int kc = split_compute_k(K);
-    // K <= 32: against the 32-column kernel the split kernel stayed ahead through 2^25; against the 64-column kernel's K = 32
-    // instantiation, which serves K <= 32 since round 4, it leads by 16 % at 2^23, ties at 2^24 and trails by 2-10 % beyond
-    // (profiles/r04_crossover_k32.log)
-    // K <= 16, where the 64-column kernel has its K = 16 instantiation and the split kernel computes on 32: level at 2^23 (1.00-1.23),
-    // 5-18 % behind at 2^24 (profiles/r04_crossover_k16.log)
-    const int lg = K <= 16 ? 23 : (kc <= 112 ? 24 : (kc <= 224 ? 23 : 22));
-    return (size_t)M * (size_t)N <= ((size_t)1 << lg);
+    const size_t mn = (size_t)M * (size_t)N;
+    const size_t lim = K <= 16 ? ((size_t)1 << 23) : (kc <= 112 ? ((size_t)3 << 22) : (kc <= 128 ? ((size_t)1 << 23) : ((size_t)1 << 21)));
+    if (mn > lim) return false;
+    if (mn >= ((size_t)1 << 22)) {
+        const int wpc = kp <= 64 ? 2 : 1;
+        const double bh = split_kernel_balance(N, M, wpc), bw = split_kernel_balance(M, N, wpc);
+        if ((bh > bw ? bh : bw) >= 1.3) return false;
+    }
+    return true;
 }
 // workgroup-level split count of the reduction dimension for Q/16 column groups over `nsc` superchunks of 128.
 // A single pair: one workgroup per CU is the target, never more workgroups than CUs (a second round costs more than the
@@ -307,7 +343,7 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
 // are preferred (32 superchunks three ways -- 11, 11, 10 -- cost 99 us where four ways cost 88).  `batch` is the restart count
 // of the whole update_div_restarts call (not of one device's or one chunk's share), so that a restart gets the same split --
 // hence the same bits -- wherever it runs.
-static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1, int wg_per_cu = 1) {
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch, int wg_per_cu) {
     const int tasks = q_valid / 16, nsc = p_extent / sc_rows;
     if (nsc <= 1) return 1;
     int S;
@@ -389,10 +425,10 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         const int qg = fused_cols_per_group(s->Kp);
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call: a restart gets the same splits wherever it runs
         s->split_batch = sb;
-        const char *rese = getenv("NMF_NSPLIT_RESIDENT");   // A/B: 2 = the splits of rounds 1-3 (512 workgroups whatever the K)
-        const int res = rese ? atoi(rese) : ((s->Kp <= 512 && !getenv("NMF_FUSED_VARIANT")) ? k16_resident(s->Kc) : 2);
-        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res);
-        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res);
+        const char *rese = getenv("NMF_NSPLIT_RESIDENT");   // A/B: 0 = the 512-workgroup rule of rounds 1-3 whatever the K
+        const int res = rese ? atoi(rese) : ((s->Kp <= 512 && !getenv("NMF_FUSED_VARIANT")) ? k16_resident(s->Kc) : 0);
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res, s->Kc / 16);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res, s->Kc / 16);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
         s->chk_groups = check_num_groups(s->Np, s->Kp);

@@ -79,7 +79,7 @@ def test_k_between_the_powers_of_two_200_iterations_vs_oracle(ng, oracle, M, N, 
 
 def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
     for (M, N, K), want in (((1024, 4096, 64), True), ((4096, 350, 128), True), ((512, 3445, 30), True), ((256, 256, 200), True), ((256, 256, 300), False),
-                            ((4096, 2048, 256), False), ((4096, 1024, 256), True),
+                            ((4096, 2048, 256), False), ((4096, 1024, 256), False), ((2048, 1024, 256), True), ((3000, 2500, 128), False), ((2048, 2048, 128), True),
                             ((4096, 65536, 64), False), ((4096, 4096, 128), False), ((4096, 2048, 128), True), ((4096, 8192, 64), False),
                             ((512, 65536, 20), False), ((512, 16384, 20), True)):
         s = ng.Solver(M, N, K)

@@ -11,8 +11,8 @@ import pytest
     ((4096, 65536, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),
     ((4096, 262144, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=262144 Kp=256 nsplit(h,w)=(1,8)"),
     ((4096, 32768, 256), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=32768 Kp=256 nsplit(h,w)=(1,8)"),
-    ((8192, 131072, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=131072 Kp=512 nsplit(h,w)=(1,4)"),
-    ((8192, 16384, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=16384 Kp=512 nsplit(h,w)=(1,4)"),
+    ((8192, 131072, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=131072 Kp=512 nsplit(h,w)=(1,2)"),
+    ((8192, 16384, 512), 1, "fused_step_kernel_k16<KT=32> Mp=8192 Np=16384 Kp=512 nsplit(h,w)=(1,2)"),
     # the reference's own problem (matrix_export.py:4-7) and the paper's example
     ((4096, 350, 128), 1, "split_step_kernel_k16<KT=8> Mp=4096 Np=384 Kp=128 splits(h,w)=(11,1) batch=1"),
     ((512, 3445, 30), 1, "split_step_kernel_k16<KT=2> Mp=512 Np=3456 Kp=32 splits(h,w)=(1,7) batch=1"),
@@ -30,8 +30,8 @@ import pytest
     ((4096, 65536, 192), 1, "fused_step_kernel_k16<KT=12> Mp=4096 Np=65536 Kp=192 nsplit(h,w)=(1,8)"),
     ((4096, 65536, 200), 1, "fused_step_kernel_k16<KT=13> Mp=4096 Np=65536 Kp=224 nsplit(h,w)=(1,8) p1_trim=2"),
     ((4096, 65536, 48), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16)"),
-    ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=19> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,8)"),     # end of round 4: every multiple of 16 up to 512
-    ((4096, 65536, 400), 1, "fused_step_kernel_k16<KT=25> Mp=4096 Np=65536 Kp=416 nsplit(h,w)=(1,8)"),
+    ((4096, 65536, 300), 1, "fused_step_kernel_k16<KT=19> Mp=4096 Np=65536 Kp=320 nsplit(h,w)=(1,4)"),     # end of round 4: every multiple of 16 up to 512
+    ((4096, 65536, 400), 1, "fused_step_kernel_k16<KT=25> Mp=4096 Np=65536 Kp=416 nsplit(h,w)=(1,4)"),
     ((4096, 65536, 37), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=2"),      # product 1 on 40 of 48
     ((4096, 65536, 36), 1, "fused_step_kernel_k16<KT=3> Mp=4096 Np=65536 Kp=64 nsplit(h,w)=(1,16) p1_trim=3"),       # product 1 on 36 of 48
     ((4096, 65536, 250), 1, "fused_step_kernel_k16<KT=16> Mp=4096 Np=65536 Kp=256 nsplit(h,w)=(1,8)"),            # one zero step only: the full chain
@@ -52,9 +52,18 @@ import pytest
     ((4096, 65536, 10), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),
     ((4096, 32768, 128), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=32768 Kp=128 nsplit(h,w)=(1,8)"),     # 1024 chunks / 12 < 96 per workgroup: the 512-workgroup rule stays
     ((65536, 4096, 64), 1, "fused_step_kernel_k16<KT=4> Mp=65536 Np=4096 Kp=64 nsplit(h,w)=(16,1)"),      # the H-step's split follows the same rule
-    ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(8,8)"),          # K <= 16: the split kernel's lead ends at 2^23 elements
+    # the split model (pick_nsplit): balance over the 256 CUs, occupancy, fixed work per workgroup, slabs
+    ((3000, 20000, 100), 1, "fused_step_kernel_k16<KT=7> Mp=3008 Np=20000 Kp=128 nsplit(h,w)=(4,16) p1_trim=3"),   # 313 column blocks: unsplit, half the chip waits (was (1,11): +42 %)
+    ((20000, 4096, 128), 1, "fused_step_kernel_k16<KT=8> Mp=20000 Np=4096 Kp=128 nsplit(h,w)=(8,4)"),
+    ((4096, 16384, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=16384 Kp=32 nsplit(h,w)=(4,16)"),            # 256 column blocks = one workgroup per CU unsplit: +27 % with four
+    ((4096, 24576, 128), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=24576 Kp=128 nsplit(h,w)=(2,8)"),
+    ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(16,16)"),          # K <= 16: the split kernel's lead ends at 2^23 elements
     ((4096, 2048, 16), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=2048 Kp=32 splits(h,w)=(2,1) batch=1"),
-    ((4096, 4096, 20), 1, "split_step_kernel_k16<KT=2> Mp=4096 Np=4096 Kp=32 splits(h,w)=(1,1) batch=1"),
+    ((4096, 4096, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(8,8) p1_trim=3"),   # K <= 112: the split kernel through 3 * 2^22 elements
+    ((2048, 4096, 20), 1, "split_step_kernel_k16<KT=2> Mp=2048 Np=4096 Kp=32 splits(h,w)=(1,2) batch=1"),
+    ((3000, 2500, 128), 1, "fused_step_kernel_k16<KT=8> Mp=3008 Np=2528 Kp=128 nsplit(h,w)=(6,5)"),            # 157 / 188 workgroups of the split kernel: a third of the chip idle
+    ((2048, 2048, 128), 1, "split_step_kernel_k16<KT=8> Mp=2048 Np=2048 Kp=128 splits(h,w)=(2,2) batch=1"),      # the same size, 256 workgroups
+    ((2048, 2048, 200), 1, "fused_step_kernel_k16<KT=13> Mp=2048 Np=2048 Kp=224 nsplit(h,w)=(8,8) p1_trim=2"),   # K > 128: the split kernel through 2^21 elements only
     ((4096, 65536, 8), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=2"),
     ((4096, 65536, 3), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=2"),
 ])
@@ -67,8 +76,8 @@ def test_plans_that_are_refused(ng):
         ng.plan_describe(1024, 1024, 700, 4)
     assert e.value.status == 7
     # round 4: a batch on the 64-column kernel (blockIdx.y = pair); the splits shrink with the batch
-    assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=19> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(8,1)"
-    assert ng.plan_describe(4096, 4096, 256, 1) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(8,8)"
+    assert ng.plan_describe(8192, 1024, 300, 4) == "fused_step_kernel_k16<KT=19> Mp=8192 Np=1024 Kp=320 nsplit(h,w)=(4,1)"
+    assert ng.plan_describe(4096, 4096, 256, 1) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(4,4)"
     assert ng.plan_describe(4096, 4096, 256, 8) == "fused_step_kernel_k16<KT=16> Mp=4096 Np=4096 Kp=256 nsplit(h,w)=(1,1)"
     with pytest.raises(ng.NmfError):
         ng.plan_describe(0, 10, 4)
