@@ -84,3 +84,36 @@ def test_plans_that_are_refused(ng):
     # explicit overrides reach the plan
     assert "splits(h,w)=(3,5)" in ng.plan_describe(2048, 2048, 64, 1, nsplit_h=3, nsplit_w=5, split_kernel=1)
     assert ng.plan_describe(1024, 4096, 64, 1, split_kernel=-1).startswith("fused_step_kernel_k16<KT=4>")
+
+
+def test_split_model_properties_over_random_shapes(ng):
+    """pick_nsplit (nmf_host.cpp) over 400 random shapes with the 64-column kernel forced: a cut never leaves a workgroup fewer than two
+    chunks of 32; a step that can reach one workgroup per CU by cutting is never left with less than half of that, alone or as a batch of
+    four; and the plan is a pure function of the shape (the same line twice)."""
+    import re
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        M, N, K = int(rng.integers(1, 70000)), int(rng.integers(1, 70000)), int(rng.integers(1, 513))
+        if rng.random() < 0.5:
+            M = int(rng.integers(1, 5000))
+        if rng.random() < 0.5:
+            N = int(rng.integers(1, 5000))
+        if (M + 31) // 32 * 32 * ((K + 31) // 32 * 32) >= 1 << 31:
+            continue
+        line = ng.plan_describe(M, N, K, 1, split_kernel=-1)
+        assert line == ng.plan_describe(M, N, K, 1, split_kernel=-1)
+        m = re.search(r"Mp=(\d+) Np=(\d+) Kp=(\d+) nsplit\(h,w\)=\((\d+),(\d+)\)", line)
+        assert m and line.startswith("fused_step_kernel_k16"), line
+        Mp, Np, _, nh, nw = (int(v) for v in m.groups())
+        for q, p, ns in ((Np, Mp, nh), (Mp, Np, nw)):
+            nq, chunks = (q + 63) // 64, p // 32
+            max_ns = max(1, min(64, chunks // 2))
+            assert 1 <= ns <= max_ns, (line, q, p)
+            assert 2 * nq * ns >= min(256, nq * max_ns), (line, q, p)
+        if M <= 65536 and N < 32768:     # a batch of four: the same bounds with four times the workgroups per cut
+            mb = re.search(r"nsplit\(h,w\)=\((\d+),(\d+)\)", ng.plan_describe(M, N, K, 4, split_kernel=-1))
+            for q, p, ns in ((Np, Mp, int(mb.group(1))), (Mp, Np, int(mb.group(2)))):
+                nq, chunks = 4 * ((q + 63) // 64), p // 32
+                max_ns = max(1, min(64, chunks // 2))
+                assert 1 <= ns <= max_ns and 2 * nq * ns >= min(256, nq * max_ns), (line, mb.group(0))
