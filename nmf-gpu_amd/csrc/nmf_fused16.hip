@@ -6,7 +6,7 @@ namespace nmf {
 
 #define NMF_K16_EXTERN(KT)                                                                                                   \
     extern template hipError_t launch_fused_k16<KT>(const FusedArgs &, bool, hipStream_t);                                   \
-    extern template hipError_t launch_check_k16<KT>(const float *, const float *, const float *, int, int, int, double *, hipStream_t, int, size_t, size_t); \
+    extern template hipError_t launch_check_k16<KT>(const float *, const float *, const float *, int, int, int, double *, hipStream_t, int, size_t, size_t, int); \
     extern template hipError_t launch_gemm_k16<KT>(const float *, const float *, float *, int, int, int, hipStream_t);
 NMF_K16_ALL(NMF_K16_EXTERN)
 #undef NMF_K16_EXTERN
@@ -46,11 +46,11 @@ hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream) {
 }
 
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
-                          int batch, size_t strideW, size_t strideH) {
+                          int batch, size_t strideW, size_t strideH, int nsplit) {
     const int kc = Kc > 0 ? Kc : Kp;
     if (!k16_shape_ok(Kp, kc)) return hipErrorInvalidValue;
     switch (kc / 16) {
-#define NMF_K16_CASE(KT) case KT: return launch_check_k16<KT>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+#define NMF_K16_CASE(KT) case KT: return launch_check_k16<KT>(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH, nsplit);
         NMF_K16_ALL(NMF_K16_CASE)
 #undef NMF_K16_CASE
         default: return hipErrorInvalidValue;

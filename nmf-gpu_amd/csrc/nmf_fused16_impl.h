@@ -437,17 +437,17 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
 
 template <int KT>
 hipError_t launch_check_k16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
-                            int batch, size_t strideW, size_t strideH) {
+                            int batch, size_t strideW, size_t strideH, int nsplit) {
     constexpr int OCC = k16_occ<KT>();
     FusedArgs a;
     a.W = W; a.H = H; a.X = X; a.U_out = nullptr; a.partials = nullptr; a.norm = nullptr;
-    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.Kc = 16 * KT; a.nsplit = 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
+    a.Mp = Mp; a.Np = Np; a.Kp = Kp; a.Kc = 16 * KT; a.nsplit = nsplit > 0 ? nsplit : 1; a.partial = 0; a.fast_divide = 0; a.x_in_range = 0;
     a.strideW = strideW; a.strideH = strideH;
     const size_t lds = k16_lds_bytes<KT>();
     hipError_t e = ensure_dynamic_lds((const void *)fused_step_kernel_k16<KT, false, false, 0, true, OCC>, lds);
     if (e != hipSuccess) return e;
     note_kernel((const void *)fused_step_kernel_k16<KT, false, false, 0, true, OCC>, stream);
-    hipLaunchKernelGGL((fused_step_kernel_k16<KT, false, false, 0, true, OCC>), dim3((Np + 63) / 64, (unsigned)batch), dim3(256), lds, stream, a, part);
+    hipLaunchKernelGGL((fused_step_kernel_k16<KT, false, false, 0, true, OCC>), dim3((unsigned)(((Np + 63) / 64) * a.nsplit), (unsigned)batch), dim3(256), lds, stream, a, part);
     return hipGetLastError();
 }
 

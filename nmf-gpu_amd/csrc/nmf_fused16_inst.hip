@@ -10,7 +10,7 @@ namespace nmf {
 
 #define NMF_K16_INSTANTIATE(KT)                                                                                              \
     template hipError_t launch_fused_k16<KT>(const FusedArgs &, bool, hipStream_t);                                          \
-    template hipError_t launch_check_k16<KT>(const float *, const float *, const float *, int, int, int, double *, hipStream_t, int, size_t, size_t); \
+    template hipError_t launch_check_k16<KT>(const float *, const float *, const float *, int, int, int, double *, hipStream_t, int, size_t, size_t, int); \
     template hipError_t launch_gemm_k16<KT>(const float *, const float *, float *, int, int, int, hipStream_t);
 
 #if NMF_K16_GROUP == 0

@@ -141,6 +141,7 @@ struct nmf_solver {
     bool xc_valid = false;         // xc3 holds the X-only terms of the check for the X now resident (computed at the first check)
     double *xc_part = nullptr, *xc3 = nullptr, *sum64 = nullptr;   // the check's X-only terms and fp64 factor sums (launch_x_consts / launch_check_compose)
     int chk_groups = 0;
+    int ns_chk = 1;                // 16-column kernel: cuts of the check's reduction over M (chk_groups = column groups x ns_chk)
     float *Z = nullptr, *WtZ = nullptr, *ZHt = nullptr;   // unfused temporaries (cuda/nmf.cu:94-96)
     float *staging = nullptr;      // unpadded upload/download staging (max of the three matrices)
     size_t staging_count = 0;
@@ -435,6 +436,14 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     } else {
         s->nsplit_w = 16;                                  // split-K slabs for the Z*H' GEMM
         s->chk_groups = reduce_num_groups((size_t)s->Mp * s->Np);
+    }
+    if (path == NMF_PATH_FUSED && fused_takes_batch(s->Kp)) {
+        // The KL check is an H-step-shaped launch (product 1 only) on the 64-column kernel whichever family iterates: six workgroups for the
+        // reference's 350 columns -- 183 us, six iterations' worth, +30 % on a run that checks every 25 iterations.  Its reduction over M is cut
+        // by the same model as a half-step's, always as for a lone problem: a restart's KL has the same bits alone and in a batch.
+        s->ns_chk = pick_nsplit(s->Np, s->Mp, 64, 1, k16_resident(s->Kc), s->Kc / 16);
+        if (s->ns_chk > s->Mp / 32) s->ns_chk = s->Mp / 32 > 0 ? s->Mp / 32 : 1;
+        s->chk_groups = check_num_groups(s->Np, s->Kp) * s->ns_chk;
     }
     return NMF_OK;
 }
@@ -1160,7 +1169,7 @@ static int check_sums_pair(nmf_solver *s, int b, double sums[3]) {
         if (s->path == NMF_PATH_FUSED) {
             const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
             NMFCHK(ensure_x_consts(s));
-            HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st));
+            HIPCHK(launch_check(Wb, Hb, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st, 1, 0, 0, s->ns_chk));
             HIPCHK(launch_check_compose(s->chk_part, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out, st));
         } else {
             const size_t mn = (size_t)s->Mp * s->Np;
@@ -1188,7 +1197,7 @@ extern "C" int nmf_solver_check_all(nmf_solver *s, double *kl, double *rel_l1) {
     // 4096 x 350 x 128: six, ~130 us) and sixteen of them one after the other were 2.7 ms of a 60 ms call -- at every
     // convergence check of a run with a threshold.  The fp64 composition (three small launches) stays per pair.
     const size_t part_stride = 3 * (size_t)s->chk_groups;
-    HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st, s->batch, (size_t)s->Mp * s->Kp, (size_t)s->Kp * s->Np));
+    HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st, s->batch, (size_t)s->Mp * s->Kp, (size_t)s->Kp * s->Np, s->ns_chk));
     for (int b = 0; b < s->batch; ++b) {
         const float *Wb = s->W + (size_t)b * s->Mp * s->Kp, *Hb = s->H + (size_t)b * s->Kp * s->Np;
         HIPCHK(launch_check_compose(s->chk_part + (size_t)b * part_stride, s->chk_groups, Wb, Hb, s->Mp, s->Np, s->Kp, s->xc3, s->sum64, s->chk_out + 3 * (size_t)b, st));
@@ -1321,7 +1330,7 @@ extern "C" int nmf_solver_time_piece(nmf_solver *s, int which, int reps, double 
                 break;
             case NMF_T_CHECK:
                 if (s->path != NMF_PATH_FUSED) return NMF_ERR_UNSUPPORTED;
-                HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st));
+                HIPCHK(launch_check(s->W, s->H, s->X, s->Mp, s->Np, s->Kp, s->Kc, s->chk_part, st, 1, 0, 0, s->ns_chk));
                 break;
             default:
 #ifdef NMF_DIAGNOSTICS   // make DIAG=1; the shipped library answers NMF_ERR_ARG

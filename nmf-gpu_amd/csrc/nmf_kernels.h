@@ -63,7 +63,7 @@ hipError_t launch_check_pair(const float *W, const float *H, const float *X, int
 bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
-                          int batch = 1, size_t strideW = 0, size_t strideH = 0);
+                          int batch = 1, size_t strideW = 0, size_t strideH = 0, int nsplit = 1);
 int        fused16_compute_k(int K);   // the multiple of 16 the 16-column kernel computes on for K <= 512, else 0
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
@@ -142,8 +142,10 @@ int        fused_pad_k(int K);             // K as the fused path pads it in HBM
 int        fused_compute_k(int K);         // K as the chosen fused kernel computes on it (FusedArgs::Kc): <= fused_pad_k(K), a multiple of 16
 // batch > 1: `batch` (W, H) pairs, strideW / strideH floats apart, in one launch (grid.y); pair b's check_num_groups triples
 // at part + 3 * check_num_groups * b.  Kp <= 512 (the batched solvers' range); the wave-pair kernel takes one pair at a time.
+// nsplit > 1 (16-column kernel only): the check's reduction over M cut like an H-step's, nsplit workgroups per 64 columns and as many
+// triples per pair (check_num_groups * nsplit) -- a 350-column problem is six workgroups otherwise
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc,
-                        double *part, hipStream_t stream, int batch = 1, size_t strideW = 0, size_t strideH = 0);
+                        double *part, hipStream_t stream, int batch = 1, size_t strideW = 0, size_t strideH = 0, int nsplit = 1);
 hipError_t launch_check_final(const double *part, int ngroups, double *out3, hipStream_t stream);
 constexpr int kXConstGroups = 1024;     // partial triples of launch_x_consts
 constexpr int kSum64Blocks = 2048;      // workgroup partials of the weighted fp64 sum over H

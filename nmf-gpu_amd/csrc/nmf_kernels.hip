@@ -51,9 +51,10 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
 }
 
 hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
-                        int batch, size_t strideW, size_t strideH) {
+                        int batch, size_t strideW, size_t strideH, int nsplit) {
     if ((Mp | Np | Kp) & 31) return hipErrorInvalidValue;
     if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    if (nsplit < 1 || (nsplit > 1 && !use_k16(Kp))) return hipErrorInvalidValue;
     if (use_pair(Kp)) {
         for (int b = 0; b < batch; ++b) {
             hipError_t e = launch_check_pair(W + (size_t)b * strideW, H + (size_t)b * strideH, X, Mp, Np, Kp, part + 3 * (size_t)check_num_groups(Np, Kp) * b, stream);
@@ -61,7 +62,7 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
         }
         return hipSuccess;
     }
-    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, Kc, part, stream, batch, strideW, strideH) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
+    return use_k16(Kp) ? launch_check16(W, H, X, Mp, Np, Kp, Kc, part, stream, batch, strideW, strideH, nsplit) : launch_check32(W, H, X, Mp, Np, Kp, part, stream, batch, strideW, strideH);
 }
 
 // two rows of H per wave and workgroup (one per half-wave): the Mp/64 workgroups of a split must cover all Kp rows
