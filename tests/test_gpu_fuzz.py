@@ -3,7 +3,7 @@ dispatch tables drawn more often (K = 16 / 17, 256 / 257, 512 / 513 ...), the au
 applies, random split overrides, either quotient, graph replay or eager launches; a few iterations each against the oracle's
 update_div (cuda/nmf.cu:118-176), W and H within 5e-6 rel-Frobenius and the KL value (cuda/matrix.cu:592) within 5e-5 (+ 1e-6 of sum(X): cancellation).
 The suite runs 60 cases of seed 0 (+ 24 through update_div_restarts and the emulated-shards driver); `python tests/test_gpu_fuzz.py <cases> <seed>
-[multi]` runs more (profiles/r04_fuzz.log: 1000 + 200)."""
+[multi|large]` runs more (profiles/r04_fuzz.log: 1000 + 200)."""
 import os
 import sys
 import time
@@ -15,13 +15,18 @@ EDGE_DIMS = (1, 16, 31, 32, 33, 64, 127, 128, 129, 1024)
 EDGE_K = (1, 3, 8, 15, 16, 17, 30, 32, 33, 48, 100, 255, 256, 257, 272, 300, 400, 496, 512, 513)
 
 
-def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
+def run_fuzz(ng, oracle, n_cases, seed, verbose=False, large=False):
+    """large: N up to 70000 and M up to 4096 (long reductions, many column blocks: the split model's other regime), two iterations"""
     rng = np.random.default_rng(seed)
     worst, fails, fam = 0.0, [], {}
     for case in range(n_cases):
         M = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
         N = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
         K = int(rng.integers(1, 601)) if rng.random() < 0.7 else int(rng.choice(EDGE_K))
+        if large:
+            M, N, K = int(rng.integers(64, 4097)), int(rng.integers(3000, 70001)), int(rng.integers(1, 301))
+            if rng.random() < 0.3:
+                M, N = N // 4, M * 4
         kw = {}
         r = rng.random()
         if r < 0.35:
@@ -34,7 +39,7 @@ def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
             kw["nsplit_w"] = int(rng.integers(1, 6))
         if rng.random() < 0.2:
             kw["fast_divide"] = 1
-        iters = int(rng.integers(1, 5))
+        iters = 2 if large else int(rng.integers(1, 5))
         graph = bool(rng.random() < 0.5)
         X, W, H = oracle.gen_problem(M, N, K, seed=int(rng.integers(0, 1 << 30)))
         s = ng.Solver(M, N, K, use_graph=graph, **kw)
@@ -47,7 +52,9 @@ def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
         Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, iters, 25)
         eW, eH = oracle.relF(Wg, Wr), oracle.relF(Hg, Hr)
         klr = oracle.kl_div(oracle.clamp(X), oracle.clamp(oracle.sgemm("nn", Wr, Hr)))
-        tol = 2e-5 if kw.get("fast_divide") else 5e-6
+        # large: a forced nsplit_w = 1 makes one fp32 accumulator chain of 60000 columns (15000 MFMA accumulations: ~eps sqrt(n) = 7e-6), and the
+        # oracle's loop has its own 5e-6 over such reductions (tests/test_gpu_update_div.py: occupancy-sized splits) -- 1e-5 there
+        tol = 2e-5 if kw.get("fast_divide") else (1e-5 if large else 5e-6)
         # KL = sum x log(x / y) - x + y is a difference of terms of size sum(x): where the fit is exact (M = 1 or N = 1: rank one) the value
         # is ~1e-12 and what the kernel's fp32 evaluation of x log y leaves is up to 3e-7 of sum(x) (measured over 600 cases, it can even
         # come out negative at an exact fit) -- the bound is relative to both
@@ -59,7 +66,7 @@ def run_fuzz(ng, oracle, n_cases, seed, verbose=False):
         if not ok:
             fails.append(line)
             print("FAIL " + line, flush=True)
-        elif verbose and case % 25 == 0:
+        elif verbose and (large or case % 25 == 0):
             print(line, flush=True)
     return fails, worst, fam
 
@@ -138,7 +145,9 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    if len(sys.argv) > 3 and sys.argv[3] == "multi":
+    if len(sys.argv) > 3 and sys.argv[3] == "large":
+        fails, worst, fam = run_fuzz(nmf_gpu_amd, oracle_mod, n, sd, verbose=True, large=True)
+    elif len(sys.argv) > 3 and sys.argv[3] == "multi":
         fails, worst, fam = run_fuzz_multi(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
     else:
         fails, worst, fam = run_fuzz(nmf_gpu_amd, oracle_mod, n, sd, verbose=True)
