@@ -427,7 +427,9 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call: a restart gets the same splits wherever it runs
         s->split_batch = sb;
         const char *rese = getenv("NMF_NSPLIT_RESIDENT");   // A/B: 0 = the 512-workgroup rule of rounds 1-3 whatever the K
-        const int res = rese ? atoi(rese) : ((s->Kp <= 512 && !getenv("NMF_FUSED_VARIANT")) ? k16_resident(s->Kc) : 0);
+        // the wave-pair kernel (K > 512) holds one workgroup per CU: the same model with r = 1 (balance and fixed work decide; 3000 x 20000 x 700
+        // 3.69 -> 2.99 ms per iteration, 3000 x 3000 x 1000 0.88 -> 0.71: profiles/r04_nsplit_model.log)
+        const int res = rese ? atoi(rese) : (s->Kp > 512 ? 1 : (!getenv("NMF_FUSED_VARIANT") ? k16_resident(s->Kc) : 0));
         s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res, s->Kc / 16);
         s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res, s->Kc / 16);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
