@@ -118,3 +118,31 @@ def test_split_model_properties_over_random_shapes(ng):
                 nq, chunks = 4 * ((q + 63) // 64), p // 32
                 max_ns = max(1, min(64, chunks // 2))
                 assert 1 <= ns <= max_ns and 2 * nq * ns >= min(256, nq * max_ns), (line, mb.group(0))
+
+
+# forced-cut sweeps measured on an MI355X (profiles/r04_nsplit_model.log; ms per iteration, the other half-step at its planned cuts):
+# (M, N, K), which half-step was swept, {cuts: ms}
+MEASURED_SWEEPS = [
+    ((4096, 16384, 64), "h", {1: 0.3134, 2: 0.2983, 3: 0.2965, 4: 0.2967}),
+    ((4096, 16384, 128), "h", {1: 0.5435, 2: 0.5339, 3: 0.5302, 4: 0.5330}),
+    ((4096, 16384, 16), "h", {1: 0.1668, 2: 0.1412, 3: 0.1340, 4: 0.1336}),
+    ((4096, 24576, 64), "h", {1: 0.5055, 2: 0.4354, 3: 0.4554, 4: 0.4339}),
+    ((4096, 24576, 128), "h", {1: 0.8939, 2: 0.7775, 3: 0.8190, 4: 0.7818}),
+    ((8192, 16384, 64), "h", {1: 0.6211, 2: 0.5723, 3: 0.5698, 4: 0.5666}),
+    ((20000, 4096, 128), "w", {1: 0.8543, 2: 0.7072, 3: 0.6772, 4: 0.6521}),
+    ((65536, 350, 128), "h", {42: 0.2541, 48: 0.3184, 64: 0.2781, 85: 0.2535, 96: 0.2825, 128: 0.2529}),
+    ((350, 65536, 128), "w", {42: 0.2324, 48: 0.2933, 64: 0.2527, 85: 0.2301, 96: 0.2571, 128: 0.2264}),
+    ((4096, 65536, 64), "w", {8: 1.1020, 16: 1.0890}),
+    ((4096, 65536, 128), "w", {8: 2.0170, 12: 2.0020}),
+]
+
+
+@pytest.mark.parametrize("shape,step,sweep", MEASURED_SWEEPS)
+def test_split_model_picks_within_3_percent_of_the_best_measured_cut(ng, shape, step, sweep):
+    """the constants of pick_nsplit's model (nmf_host.cpp) against the sweeps they were fitted to: whoever retunes them keeps the
+    planned cut count among the measured ones and within 3 % of the fastest"""
+    import re
+    m = re.search(r"nsplit\(h,w\)=\((\d+),(\d+)\)", ng.plan_describe(*shape, 1, split_kernel=-1))
+    ns = int(m.group(1 if step == "h" else 2))
+    assert ns in sweep, (shape, step, ns, sorted(sweep))
+    assert sweep[ns] <= 1.03 * min(sweep.values()), (shape, step, ns, sweep[ns], min(sweep.values()))
