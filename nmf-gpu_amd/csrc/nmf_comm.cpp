@@ -169,15 +169,9 @@ static void arm_fault(nmf_comm *c) {
     if (e && sscanf(e, "%d:%ld", &r, &at) == 2 && r == c->rank) c->fail_at = at;
 }
 
-struct EmuPtrs { const void *p[kMaxEmu]; };
-template <typename T>
-__global__ __launch_bounds__(256) void emu_sum_kernel(EmuPtrs src, int n, T *__restrict__ dst, size_t count) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        T s = reinterpret_cast<const T *>(src.p[0])[i];
-        for (int r = 1; r < n; ++r) s += reinterpret_cast<const T *>(src.p[r])[i];   // rank order: the same bits on every rank
-        dst[i] = s;
-    }
-}
+// the device-side sum of the emulated group lives with the other kernels (nmf_kernels.hip): this file is host code only, and the
+// ThreadSanitizer build of it (tests/cpu_sanitize/) is a plain C++ compile with no device pass
+static_assert(kMaxEmu == NMF_EMU_MAX_RANKS, "EmuGroup and the emulation kernel agree on the rank limit");
 
 extern "C" int nmf_comm_get_unique_id(unsigned char id[NMF_COMM_ID_BYTES]) {
     if (!id) return NMF_ERR_ARG;
@@ -372,14 +366,12 @@ static int emu_allreduce(nmf_comm *c, T *buf, size_t count, hipStream_t stream) 
     g.buf[r] = buf;
     if (hipEventRecord(g.ev1[r], stream) != hipSuccess) return NMF_ERR_HIP;
     if (!g.rendezvous(nmf_comm_timeout_s())) return NMF_ERR_COMM;          // every operand is enqueued and published
-    EmuPtrs ptrs;
+    const void *ptrs[kMaxEmu] = {};
     for (int h = 0; h < n; ++h) {
-        ptrs.p[h] = g.buf[h];
+        ptrs[h] = g.buf[h];
         if (h != r && hipStreamWaitEvent(stream, g.ev1[h], 0) != hipSuccess) return NMF_ERR_HIP;
     }
-    size_t grid = (count + 255) / 256;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(emu_sum_kernel<T>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (T *)g.tmp[r], count);
+    if (nmf_emu_sum_launch(ptrs, n, g.tmp[r], count, sizeof(T) == 8, stream) != hipSuccess) return NMF_ERR_HIP;
     if (hipEventRecord(g.ev2[r], stream) != hipSuccess) return NMF_ERR_HIP;
     if (!g.rendezvous(nmf_comm_timeout_s())) return NMF_ERR_COMM;          // every rank has read every operand ...
     for (int h = 0; h < n; ++h)

@@ -1,7 +1,7 @@
 // nmf_comm.h -- thin RCCL wrapper for N-sharded runs (internal).  RCCL is dlopen()ed on first
 // use so that single-GPU users of libnmf_mi355x.so never load it.
 #pragma once
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
 #include <stddef.h>
 
 struct nmf_comm;
@@ -37,3 +37,8 @@ long nmf_comm_heartbeat(const nmf_comm *c);
 
 // the calling thread's nmf_last_error() text (rank threads hand their message to the thread that called update_div_ex)
 void nmf_internal_set_error(const char *msg);
+
+// dst[i] = src[0][i] + src[1][i] + ... + src[n - 1][i] in rank order (the same bits on every rank), f32 or f64: the emulated
+// group's reduction, launched on `stream` (nmf_kernels.hip).  n <= NMF_EMU_MAX_RANKS.
+#define NMF_EMU_MAX_RANKS 8
+hipError_t nmf_emu_sum_launch(const void *const *src, int n, void *dst, size_t count, bool f64, hipStream_t stream);

@@ -540,3 +540,28 @@ hipError_t launch_unpad_copy(float *dst, int rows, int cols, const float *src, i
 }
 
 }  // namespace nmf
+
+// ---------------------------------------------------------------- the emulated communicator group's reduction (nmf_comm.h)
+#include "nmf_comm.h"
+namespace {
+struct EmuPtrs { const void *p[NMF_EMU_MAX_RANKS]; };
+template <typename T>
+__global__ __launch_bounds__(256) void emu_sum_kernel(EmuPtrs src, int n, T *__restrict__ dst, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        T s = reinterpret_cast<const T *>(src.p[0])[i];
+        for (int r = 1; r < n; ++r) s += reinterpret_cast<const T *>(src.p[r])[i];   // rank order: the same bits on every rank
+        dst[i] = s;
+    }
+}
+}  // namespace
+hipError_t nmf_emu_sum_launch(const void *const *src, int n, void *dst, size_t count, bool f64, hipStream_t stream) {
+    if (n < 1 || n > NMF_EMU_MAX_RANKS) return hipErrorInvalidValue;
+    EmuPtrs ptrs = {};
+    for (int r = 0; r < n; ++r) ptrs.p[r] = src[r];
+    size_t grid = (count + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    if (f64) hipLaunchKernelGGL(emu_sum_kernel<double>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (double *)dst, count);
+    else     hipLaunchKernelGGL(emu_sum_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (float *)dst, count);
+    return hipGetLastError();
+}

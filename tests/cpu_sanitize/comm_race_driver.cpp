@@ -1,6 +1,6 @@
 // Race test of nmf_comm_abort against ranks on their way into / inside ncclAllReduce (round-3 VERDICT, weak 5: the abort used to
 // free a communicator handle that a peer thread had just read without a lock).  Links a ThreadSanitizer build of the product's
-// nmf_comm.cpp (host side only) against tests/helpers/fake_rccl.c posing as librccl.so.1; no GPU, no HIP call is made.
+// nmf_comm.cpp (host side only) against tests/cpu_sanitize/fake_rccl.c posing as librccl.so.1; no GPU, no HIP call is made.
 //   argv[1] = rounds.  Every round: an ncclCommInitAll group of 4, one thread per rank calling the f32 all-reduce in a loop,
 //   an abort from a fifth thread (or from one of the ranks, via the NMF_FAULT_ALLREDUCE-style failure path) at a random time.
 #include "../../nmf-gpu_amd/csrc/nmf_comm.h"
@@ -14,6 +14,8 @@
 #include <vector>
 
 void nmf_internal_set_error(const char *) {}
+// the emulated group's device-side sum (nmf_kernels.hip) is not part of this host-only build and is never reached here
+hipError_t nmf_emu_sum_launch(const void *const *, int, void *, size_t, bool, hipStream_t) { return hipErrorNotSupported; }
 
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 100;
