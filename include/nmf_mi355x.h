@@ -291,6 +291,11 @@ int  nmf_comm_probe(nmf_comm *c, double timeout_s);
 /* one line: version and path of the RCCL library actually loaded, and the rccl.h version this library was compiled against
  * (a different major version is refused at load) */
 int  nmf_comm_library_info(char *buf, int buflen);
+/* Diagnostics.  A wait on a sharded run's stream makes no HIP call while it waits (it watches a pinned word the device writes behind
+ * the awaited work) and closes with one hipStreamSynchronize whose status is final -- except hipErrorStreamCaptureUnsupported, which
+ * reports a stream capture elsewhere in the process rather than this stream and is asked again up to three times.  This counts those
+ * (process-wide); the library serialises its own captures, so the expected value is 0. */
+long nmf_comm_capture_refusals(void);
 
 /* 1 if sharding an M x N x K problem over n_devices GPUs amortises the per-iteration all-reduce (what NMF_DEVICES=auto uses) */
 int  nmf_worth_sharding(int M, int N, int K, int n_devices);

@@ -22,7 +22,7 @@ __all__ = [
     "matrix_multiply", "matrix_multiply_AtB", "matrix_multiply_ABt", "element_multiply", "element_divide",
     "row_divide", "col_divide", "set_epsilon", "sum_cols", "sum_rows", "kl_divergence", "diff_norm",
     "Comm", "device_count", "device_name", "lib", "LIB_PATH", "PATH_AUTO", "PATH_FUSED", "PATH_UNFUSED",
-    "T_NAMES", "declared_symbols", "comm_library_info", "record_kernels", "last_kernel", "plan_describe",
+    "T_NAMES", "declared_symbols", "comm_library_info", "comm_capture_refusals", "record_kernels", "last_kernel", "plan_describe",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -122,6 +122,7 @@ _SIGS = [
     ("nmf_comm_destroy", None, [C.c_void_p]),
     ("nmf_comm_probe", C.c_int, [C.c_void_p, C.c_double]),
     ("nmf_comm_library_info", C.c_int, [C.c_char_p, C.c_int]),
+    ("nmf_comm_capture_refusals", C.c_long, []),
     ("nmf_worth_sharding", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("nmf_plan_describe", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_opts), C.c_char_p, C.c_int]),
     ("nmf_debug_record_kernels", C.c_int, [C.c_int]),
@@ -412,6 +413,11 @@ def comm_library_info() -> str:
     buf = C.create_string_buffer(768)
     lib().nmf_comm_library_info(buf, 768)
     return buf.value.decode()
+
+
+def comm_capture_refusals() -> int:
+    """process-wide count of waits whose closing hipStreamSynchronize was refused because of a capture elsewhere (expected: 0)"""
+    return int(lib().nmf_comm_capture_refusals())
 
 
 def plan_describe(M: int, N: int, K: int, batch: int = 1, **opts) -> str:

@@ -156,6 +156,10 @@ struct nmf_comm {
     std::atomic<long> beat{0};       // nmf_comm_heartbeat
     // fault injection for the tests (NMF_FAULT_ALLREDUCE=<rank>:<call>): that f32 all-reduce call of that rank fails
     long calls = 0, fail_at = 0;
+    // nmf_comm_wait: a pinned host word the device stores a ticket into behind the awaited work (allocated at the first wait)
+    unsigned *ticket_word = nullptr;
+    unsigned ticket = 0;
+    ~nmf_comm() { if (ticket_word) (void)hipHostFree(ticket_word); }
 };
 
 double nmf_comm_timeout_s() {
@@ -322,25 +326,48 @@ bool nmf_comm_aborted(const nmf_comm *c) {
     return c->grp ? c->grp->aborted.load() : false;
 }
 
+// Waiting for a stream with a deadline, WITHOUT polling it through the HIP API.
+//
+// Until round 5 this loop called hipStreamQuery every few microseconds, and once -- in the rehearsal that runs several host threads
+// of one process side by side, each capturing hipGraphs with RCCL all-reduces inside -- the query answered with an error on the
+// caller's own, healthy stream.  What this HIP build (libamdhip64.so.7.2.70200) can answer from hipStreamQuery, read off its code:
+// hipErrorNotReady / hipSuccess; the process-wide sticky status every API entry starts with (a device fault: never transient);
+// hipErrorInvalidHandle from the look-up of the stream in the runtime's set of live streams; and hipErrorStreamCaptureUnsupported
+// from the capture rule (a stream that is not capturing is refused while a capture this thread must respect is under way).  The last
+// two do not describe the polled stream: they describe the runtime's stream set and capture lists at that instant, which the OTHER
+// threads were changing (hipStreamBeginCapture / EndCapture, RCCL forking its internal stream into the capture on ncclAllReduce,
+// hipGraphInstantiate, pooled-stream creation).  A poll that asks thousands of times per wait is the call most exposed to them.
+// So the wait no longer asks the runtime anything while it waits: a one-thread kernel behind the awaited work stores a ticket into
+// a pinned host word, the host watches that word, and ONE hipStreamSynchronize -- on a stream that has already drained -- collects
+// the stream's status, which is taken at face value (with one named exception, below).  Captures are also serialised process-wide and,
+// inside one sharded call, finished on every rank before any rank replays (nmf_host.cpp: capture_graph; nmf_multi.cpp: the set-up gate).
+namespace {
+std::atomic<long> g_capture_refusals{0};
+}
+extern "C" long nmf_comm_capture_refusals(void) { return g_capture_refusals.load(); }
+
+static int wait_ticket_init(nmf_comm *c) {
+    if (c->ticket_word) return NMF_OK;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return NMF_ERR_NOMEM; }
+    *(volatile unsigned *)p = 0u;
+    c->ticket_word = (unsigned *)p;
+    return NMF_OK;
+}
+
 int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char *what) {
     if (!c) return hipStreamSynchronize(stream) == hipSuccess ? NMF_OK : NMF_ERR_HIP;
+    if (wait_ticket_init(c) != NMF_OK) return NMF_ERR_NOMEM;
+    const unsigned ticket = ++c->ticket;
+    {
+        const hipError_t e = nmf_flag_store_launch(c->ticket_word, ticket, stream);
+        if (e != hipSuccess) { fprintf(stderr, "nmf_comm: rank %d: cannot enqueue the completion ticket behind %s: %s\n", c->rank, what ? what : "a collective", hipGetErrorName(e)); return NMF_ERR_HIP; }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     bool expired = false;
-    int odd_answers = 0;
     for (int spins = 0;; ++spins) {
         c->beat.fetch_add(1, std::memory_order_relaxed);
-        const hipError_t q = hipStreamQuery(stream);
-        if (q == hipSuccess) return nmf_comm_aborted(c) ? NMF_ERR_COMM : NMF_OK;
-        if (q != hipErrorNotReady) {
-            // Seen once in four runs of the concurrent-ranks rehearsal (several host threads of one process, each polling its own stream
-            // while the others capture hipGraphs): hipStreamQuery answered with an error although nothing was wrong with this stream --
-            // the next query was fine.  An error that persists for 200 queries over >= 0.2 s is real; it is named either way.
-            (void)hipGetLastError();
-            if (++odd_answers == 1) fprintf(stderr, "nmf_comm: rank %d: hipStreamQuery answered %s (%s) while waiting for %s; asking again\n", c->rank, hipGetErrorName(q), hipGetErrorString(q), what ? what : "a collective");
-            if (odd_answers > 200) { fprintf(stderr, "nmf_comm: rank %d: hipStreamQuery keeps answering %s\n", c->rank, hipGetErrorName(q)); return NMF_ERR_HIP; }
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
-            continue;
-        }
+        if (__atomic_load_n(c->ticket_word, __ATOMIC_ACQUIRE) == ticket) break;   // the device wrote it: everything in front of it has finished
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!expired && (el > timeout_s || nmf_comm_aborted(c))) {
             if (el > timeout_s) fprintf(stderr, "nmf_comm: rank %d: %s did not complete within %.1f s; aborting the communicator group\n", c->rank, what ? what : "a collective", timeout_s);
@@ -350,6 +377,17 @@ int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char 
         if (expired && el > timeout_s + 10.0) return NMF_ERR_COMM;   // the aborted collective should have left the stream by now
         if (spins < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
+    // The stream has drained; this returns at once and its answer is the stream's real status.  hipErrorStreamCaptureUnsupported alone is
+    // asked again (it reports a capture elsewhere, not this stream), at most three times, and counted: nmf_comm_capture_refusals() must
+    // stay 0 in the tests.  Anything else is an error of this run and ends it, by name.
+    for (int attempt = 0;; ++attempt) {
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) break;
+        fprintf(stderr, "nmf_comm: rank %d: hipStreamSynchronize after %s: %s (%s)\n", c->rank, what ? what : "a collective", hipGetErrorName(e), hipGetErrorString(e));
+        if (e == hipErrorStreamCaptureUnsupported && attempt < 3) { g_capture_refusals.fetch_add(1); std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+        return NMF_ERR_HIP;
+    }
+    return (expired || nmf_comm_aborted(c)) ? NMF_ERR_COMM : NMF_OK;
 }
 
 template <typename T>

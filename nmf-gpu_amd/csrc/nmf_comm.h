@@ -24,7 +24,8 @@ void nmf_comm_abort(nmf_comm *c);
 bool nmf_comm_aborted(const nmf_comm *c);
 // deadline (seconds) of nmf_comm_wait and of the emulated group's host rendezvous: NMF_COMM_TIMEOUT_S, default 30
 double nmf_comm_timeout_s();
-// wait for `stream` to drain, polling, for at most `timeout_s`.  On expiry (a rank that never arrived at a collective leaves
+// wait for `stream` to drain, for at most `timeout_s`, watching a pinned host word the device stores a ticket into (no HIP call
+// while waiting: see nmf_comm.cpp).  On expiry (a rank that never arrived at a collective leaves
 // its peers' all-reduce kernels spinning) or when another rank has aborted the group: abort the group, give the stream a
 // few seconds to drain its now-aborted collective, and return NMF_ERR_COMM.  c == nullptr: plain hipStreamSynchronize.
 int nmf_comm_wait(nmf_comm *c, hipStream_t stream, double timeout_s, const char *what);
@@ -42,3 +43,7 @@ void nmf_internal_set_error(const char *msg);
 // group's reduction, launched on `stream` (nmf_kernels.hip).  n <= NMF_EMU_MAX_RANKS.
 #define NMF_EMU_MAX_RANKS 8
 hipError_t nmf_emu_sum_launch(const void *const *src, int n, void *dst, size_t count, bool f64, hipStream_t stream);
+// *word_host_mapped = value (system-scope release store) by one thread on `stream`: the completion ticket of nmf_comm_wait (nmf_kernels.hip)
+hipError_t nmf_flag_store_launch(unsigned *word_host_mapped, unsigned value, hipStream_t stream);
+// how often a wait's closing hipStreamSynchronize was refused because of a capture elsewhere in the process (expected: never)
+// (declared in include/nmf_mi355x.h: nmf_comm_capture_refusals)

@@ -493,7 +493,7 @@ static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, co
         if (s->nsplit_h > 1) pc = (size_t)s->nsplit_h * kn;
         if ((size_t)s->nsplit_w * mk > pc) pc = (size_t)s->nsplit_w * mk;   // W-step may always need slabs (sharded; a batch: always)
         ar.reserve((void **)&s->partials, (pc * batch) * sizeof(float));
-        if ((s->nsplit_w > 1 || batch > 1) && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp * batch) * sizeof(float));
+        if ((s->nsplit_w > 1 || s->split_batch > 1) && fused_streams_vsum(s->Mp, s->Kp)) ar.reserve((void **)&s->vsum_part, ((size_t)s->nsplit_w * s->Kp * batch) * sizeof(float));
     } else {
         ar.reserve((void **)&s->Z, (mn) * sizeof(float));
         ar.reserve((void **)&s->WtZ, (kn) * sizeof(float));
@@ -940,7 +940,9 @@ static int enqueue_update_w(nmf_solver *s) {
     if (s->path == NMF_PATH_FUSED) {
         FusedArgs a = fused_args(s);
         a.nsplit = s->nsplit_w;
-        if (s->batch > 1) {
+        if (s->split_batch > 1) {
+            // (keyed on the restart count of the WHOLE call, not on this solver's share of it: a worker dealt a single restart of a
+            //  batched call must run the kernels -- and the summation order of the normaliser -- its restart gets in the one-device call)
             // every pair in one launch: raw slabs (also with nsplit_w == 1), finished per pair by the apply that also leaves the next
             // H-step's normaliser.  The row sums of H come off the stream where the W-step's workgroups cover all K rows (K <= M / 16:
             // no row-sum launches), else from the two-level row-sum kernels with a pair dimension.
@@ -1036,8 +1038,18 @@ extern "C" int nmf_solver_set_partial_buffer(nmf_solver *s, float *dev_ptr, size
 
 // cuda/nmf.cu:100-115: capture iterations, replay them.
 constexpr int kGraphIters[3] = {32, 8, 1};
+// One capture at a time in this process.  The capture itself is thread-local (no other thread's HIP calls are restricted by it), but
+// what runs between Begin and End touches process-wide runtime state: RCCL forks its internal stream into the capture inside
+// ncclAllReduce, the runtime registers and unregisters capturing streams, hipGraphInstantiate builds its own streams.  Several ranks of one
+// call (nmf_multi.cpp) or several independent calls doing that side by side is the one configuration in which a HIP call on an
+// unrelated stream has been seen to fail (nmf_comm.cpp: nmf_comm_wait); a capture takes 1-2 ms, so they take turns.  The lock is
+// bounded: should an RCCL build ever make a captured enqueue wait for a peer rank of the same process, the peer gives up waiting
+// for the lock after 5 s and captures beside it, as before.
+static std::timed_mutex g_capture_mu;
 static int capture_graph(nmf_solver *s, int iterations, hipGraph_t *graph, hipGraphExec_t *exec) {
     const double t0 = now_s();
+    std::unique_lock<std::timed_mutex> turn(g_capture_mu, std::defer_lock);
+    if (!turn.try_lock_for(std::chrono::seconds(5))) fprintf(stderr, "nmf: another thread has been capturing a hipGraph for 5 s; capturing beside it\n");
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     int st = NMF_OK;
     for (int i = 0; i < iterations && st == NMF_OK; ++i) {
@@ -1077,7 +1089,7 @@ static int ensure_level(nmf_solver *s, int li) {
 static bool w_step_refreshes_normW(const nmf_solver *s) {
     if (s->Mp > kMaxRowsApplyColsum) return false;
     if (s->split) return false;   // the split kernel sums its normaliser from the factor it streams
-    return s->comm ? true : (s->path == NMF_PATH_FUSED && (s->nsplit_w > 1 || s->batch > 1));
+    return s->comm ? true : (s->path == NMF_PATH_FUSED && (s->nsplit_w > 1 || s->split_batch > 1));
 }
 
 extern "C" int nmf_solver_iterate(nmf_solver *s, int iters) {
@@ -1138,6 +1150,7 @@ extern "C" int nmf_solver_prepare(nmf_solver *s, int iters) {
     }
     if (st == NMF_OK && !s->level[2].ready) st = ensure_level(s, 2);
     s->normW_fresh = fresh;
+    if (st == NMF_ERR_COMM) return st;   // the communicator's first all-reduce did not complete: nothing to fall back to
     if (st != NMF_OK) { (void)hipGetLastError(); g_err[0] = 0; }   // iterate() will find out for itself and fall back
     return NMF_OK;
 }

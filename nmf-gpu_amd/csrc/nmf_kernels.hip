@@ -565,3 +565,14 @@ hipError_t nmf_emu_sum_launch(const void *const *src, int n, void *dst, size_t c
     else     hipLaunchKernelGGL(emu_sum_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, ptrs, n, (float *)dst, count);
     return hipGetLastError();
 }
+
+// the completion ticket of nmf_comm_wait: everything enqueued on the stream before this has finished when the host sees `value`
+namespace {
+__global__ void flag_store_kernel(unsigned *word, unsigned value) {
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+hipError_t nmf_flag_store_launch(unsigned *word_host_mapped, unsigned value, hipStream_t stream) {
+    hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(1), 0, stream, word_host_mapped, value);
+    return hipGetLastError();
+}

@@ -16,6 +16,7 @@
 void nmf_internal_set_error(const char *) {}
 // the emulated group's device-side sum (nmf_kernels.hip) is not part of this host-only build and is never reached here
 hipError_t nmf_emu_sum_launch(const void *const *, int, void *, size_t, bool, hipStream_t) { return hipErrorNotSupported; }
+hipError_t nmf_flag_store_launch(unsigned *, unsigned, hipStream_t) { return hipErrorNotSupported; }
 
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 100;

@@ -183,13 +183,15 @@ def _pairs(M, N, K, R, seed):
 
 
 @pytest.mark.parametrize("M,N,K,R,devices,thresh", [(512, 1000, 30, 7, [0, 0], 0.0), (1024, 350, 128, 5, [0, 0, 0], 2e-3),
-                                                     (256, 2048, 320, 3, [0, 0], 0.0)])
+                                                     (256, 2048, 320, 3, [0, 0], 0.0), (2048, 2048, 256, 3, [0, 0], 0.0)])
 def test_restarts_dealt_to_several_workers_equal_the_one_device_call_bit_for_bit(ng, oracle, M, N, K, R, devices, thresh):
     """SURVEY 8f4 / 8e 'replicas only': update_div_restarts(n_devices = G, devices = [...]) deals restart i to worker i % G --
     a host thread, a batched solver, a copy of X each; no communicator.  Two (three) workers on the one GPU of the box are
     what can be run of it here.  Every restart must come out exactly as in the one-device call (same kernels, same split
-    counts: the split is chosen from the restart count of the whole call), with the same KL values and the same winner;
-    K = 320 takes the stream-lane mechanism instead of the batched grid."""
+    counts: the split is chosen from the restart count of the whole call), with the same KL values and the same winner.
+    K = 320 and 2048 x 2048 x 256 run batched on the 64-column kernel; in the latter (K <= M / 8) the W-step's normaliser comes off
+    the stream (vsum_part), and with three restarts over two workers one worker is dealt a SINGLE restart: it must take the batched
+    route too (round-4 ADVICE: it used to fall to the lone-problem route, whose row sums are summed in another order)."""
     X, _, _ = oracle.gen_problem(M, N, K, seed=41)
     Ws, Hs = _pairs(M, N, K, R, 42)
     W1, H1 = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
@@ -287,6 +289,9 @@ def test_concurrent_ranks_each_with_an_rccl_communicator_capture_and_replay_thei
     for t in th:
         t.join()
     assert len(together) == len(shapes)          # no thread died in the driver
+    # a wait makes no HIP call while it waits and its closing synchronize was never refused because of a capture elsewhere
+    # (round-4 VERDICT weak 2: the poll used to go through hipStreamQuery and swallowed up to 200 errors of any kind)
+    assert ng.comm_capture_refusals() == 0
     for i in range(len(shapes)):
         run(i, alone)
     for i, (M, N, K) in enumerate(shapes):
