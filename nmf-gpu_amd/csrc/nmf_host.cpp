@@ -561,7 +561,7 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
-    else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<NBH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 128, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<KTH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kc / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else if (!getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
                                                                s->p1_trim == 3 ? " p1_trim=3" : (s->p1_trim == 2 ? " p1_trim=2" : ""));
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);

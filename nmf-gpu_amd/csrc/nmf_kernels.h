@@ -56,9 +56,12 @@ hipError_t launch_fused_step(const FusedArgs &a, bool wstep, hipStream_t stream)
 // of 32 above; nmf_fused32.hip: Kp = 32 / 64 / 128 / 256 under NMF_FUSED_VARIANT=3 only)
 hipError_t launch_fused16(const FusedArgs &a, bool wstep, hipStream_t stream);
 hipError_t launch_fused32(const FusedArgs &a, bool wstep, hipStream_t stream);
-// 512 < Kp <= 1024 (a multiple of 128): two waves share 16 owned columns and split K (nmf_pair16.hip)
+// 512 < K <= 1024: two waves share 16 owned columns and split K (nmf_pair16_impl.h); computes on a.Kc = pair_compute_k(K), a multiple
+// of 32, with the factors padded to a.Kp = pair_pad_k(K), a multiple of 64, in HBM
 hipError_t launch_fused_pair(const FusedArgs &a, bool wstep, hipStream_t stream);
-hipError_t launch_check_pair(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream);
+hipError_t launch_check_pair(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream);
+int pair_compute_k(int K);
+int pair_pad_k(int K);
 // C = A * B through product 1 of the 16-column kernel (the W*H shape: tall A, K <= 512), see nmf_fused16.hip
 bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc);
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);

@@ -57,7 +57,7 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
     if (nsplit < 1 || (nsplit > 1 && !use_k16(Kp))) return hipErrorInvalidValue;
     if (use_pair(Kp)) {
         for (int b = 0; b < batch; ++b) {
-            hipError_t e = launch_check_pair(W + (size_t)b * strideW, H + (size_t)b * strideH, X, Mp, Np, Kp, part + 3 * (size_t)check_num_groups(Np, Kp) * b, stream);
+            hipError_t e = launch_check_pair(W + (size_t)b * strideW, H + (size_t)b * strideH, X, Mp, Np, Kp, Kc, part + 3 * (size_t)check_num_groups(Np, Kp) * b, stream);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -77,11 +77,11 @@ int fused_pad_k(int K) {
     if (k32 <= 32) return 32;
     if (k32 <= 256 && fused_variant() != 0) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
     if (k32 <= 512) return k32;
-    const int k128 = (K + 127) & ~127;        // the pair kernel splits K in two halves of whole 64-blocks
-    return k128 <= kMaxFusedK ? k128 : 0;
+    return K <= kMaxFusedK ? pair_pad_k(K) : 0;   // the wave-pair kernel: 64 in HBM (whole staged pieces), 32 in its MFMAs (pair_compute_k)
 }
 int fused_compute_k(int K) {
     const int kp = fused_pad_k(K);
+    if (kp && use_pair(kp)) return pair_compute_k(K);
     if (!kp || !use_k16(kp)) return kp;
     return fused16_compute_k(K);
 }

@@ -121,16 +121,32 @@ def test_every_instantiation_of_the_split_kernel(ng, oracle, recording):
 
 
 def test_every_instantiation_of_the_wave_pair_kernel(ng, oracle, recording):
-    """fused_step_kernel_pair<NBH, WSTEP, PARTIAL, DIV, CHECK> for K = 640, 768, 896, 1024.  (The 32-column kernel
+    """fused_step_kernel_pair<KTH, WSTEP, PARTIAL, DIV, CHECK> for every K = 32 KTH from 544 to 1024 (round 5: until then K = 640, 768,
+    896, 1024 only, and K = 520 ran padded to 640).  Odd KTH: a wave's half of K ends in a remainder block of product 1 (runs of 4, 8 or
+    12 per lane group), the factors are padded to the next multiple of 64 in HBM and the LDS image holds two ds_writes per thread
+    more than product 2 has slots; the slab epilogue writes the 32 padding rows as zeros.  (The 32-column kernel
     fused_step_kernel_v3 is reachable only through NMF_FUSED_VARIANT, an A/B switch read once per process, since round 4 gave K <= 32
     to the 64-column kernel: tests/test_gpu_update_div.py::test_32_column_kernel_family_via_env_override runs it in a subprocess.)"""
     seen = set()
-    for K, ns, fd in itertools.product((640, 768, 896, 1024), (1, 2), (0, 1)):
-        _half_steps(ng, oracle, 96, 160, K, seen, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
+    kths = tuple(range(17, 33))
+    for kth, ns, fd in itertools.product(kths, (1, 2), (0, 1)):
+        _half_steps(ng, oracle, 96, 160, 32 * kth, seen, nsplit_h=ns, nsplit_w=ns, fast_divide=fd)
     want = set()
-    for nbh in ("5", "6", "7", "8"):
+    for kth in kths:
         for w, p, d in itertools.product(("false", "true"), ("false", "true"), ("0", "1")):
-            want.add(("fused_step_kernel_pair", (nbh, w, p, d, "false")))
-        want.add(("fused_step_kernel_pair", (nbh, "false", "false", "0", "true")))
+            want.add(("fused_step_kernel_pair", (str(kth), w, p, d, "false")))
+        want.add(("fused_step_kernel_pair", (str(kth), "false", "false", "0", "true")))
     got_pair = {(n, a[:5]) for n, a in seen if n == "fused_step_kernel_pair"}
     assert want <= got_pair, sorted(want - got_pair)
+
+
+def test_a_logical_k_above_512_runs_the_next_multiple_of_32(ng, oracle, recording):
+    """K = 520 computes on 544 (KTH = 17, factors padded to 576), 700 on 704, 900 on 928 (padded to 960), 1000 on 1024: the reference's
+    granularity (PAD_MULT = 32, cuda/matrix.cuh:7; cuda/matrix.cu:88-95).  With two slabs per half-step, so that the zero rows the slab
+    epilogue writes for the padding are read by the apply kernels."""
+    seen = set()
+    for K, kth in ((520, 17), (700, 22), (900, 29), (1000, 32), (545, 18)):
+        for ns in (1, 2):
+            seen.clear()
+            _half_steps(ng, oracle, 96, 160, K, seen, nsplit_h=ns, nsplit_w=ns)
+            assert {a[0] for n, a in seen if n == "fused_step_kernel_pair"} == {str(kth)}, (K, seen)

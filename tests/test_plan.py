@@ -43,8 +43,8 @@ import pytest
     ((4096, 350, 100), 16, "split_step_kernel_k16<KT=7> Mp=4096 Np=384 Kp=128 splits(h,w)=(2,1) batch=16"),
     ((1024, 4096, 48), 1, "split_step_kernel_k16<KT=3> Mp=1024 Np=4096 Kp=64 splits(h,w)=(1,4) batch=1"),
     # the K ranges of the other families
-    ((4096, 65536, 1024), 1, "fused_step_kernel_pair<NBH=8> Mp=4096 Np=65536 Kp=1024 nsplit(h,w)=(1,2)"),
-    ((4096, 65536, 600), 1, "fused_step_kernel_pair<NBH=5> Mp=4096 Np=65536 Kp=640 nsplit(h,w)=(1,2)"),
+    ((4096, 65536, 1024), 1, "fused_step_kernel_pair<KTH=32> Mp=4096 Np=65536 Kp=1024 nsplit(h,w)=(1,2)"),
+    ((4096, 65536, 600), 1, "fused_step_kernel_pair<KTH=19> Mp=4096 Np=65536 Kp=640 nsplit(h,w)=(1,2)"),
     ((4096, 65536, 2000), 1, "unfused operators (gemm_kernel), Mp=4096 Np=65536 Kp=2016"),
     ((4096, 65536, 30), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16)"),      # round 4: the 64-column kernel below K = 48 too
     ((4096, 65536, 20), 1, "fused_step_kernel_k16<KT=2> Mp=4096 Np=65536 Kp=32 nsplit(h,w)=(1,16) p1_trim=3"),
@@ -55,7 +55,7 @@ import pytest
     # the split model (pick_nsplit): balance over the 256 CUs, occupancy, fixed work per workgroup, slabs
     ((3000, 20000, 100), 1, "fused_step_kernel_k16<KT=7> Mp=3008 Np=20000 Kp=128 nsplit(h,w)=(4,16) p1_trim=3"),   # 313 column blocks: unsplit, half the chip waits (was (1,11): +42 %)
     ((20000, 4096, 128), 1, "fused_step_kernel_k16<KT=8> Mp=20000 Np=4096 Kp=128 nsplit(h,w)=(8,4)"),
-    ((3000, 20000, 700), 1, "fused_step_kernel_pair<NBH=6> Mp=3008 Np=20000 Kp=768 nsplit(h,w)=(2,8)"),         # the wave-pair kernel: one workgroup per CU, the same model (was (1,6): +23 %)
+    ((3000, 20000, 700), 1, "fused_step_kernel_pair<KTH=22> Mp=3008 Np=20000 Kp=704 nsplit(h,w)=(2,8)"),         # the wave-pair kernel: one workgroup per CU, the same model (was (1,6): +23 %)
     ((4096, 16384, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=16384 Kp=32 nsplit(h,w)=(4,16)"),            # 256 column blocks = one workgroup per CU unsplit: +27 % with four
     ((4096, 24576, 128), 1, "fused_step_kernel_k16<KT=8> Mp=4096 Np=24576 Kp=128 nsplit(h,w)=(2,8)"),
     ((4096, 4096, 16), 1, "fused_step_kernel_k16<KT=1> Mp=4096 Np=4096 Kp=32 nsplit(h,w)=(16,16)"),          # K <= 16: the split kernel's lead ends at 2^23 elements

@@ -28,10 +28,11 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nmf-gpu_amd", "csrc")
-# (label, source, extra flags): the instantiations of the 64-column and of the split kernel are one source each, compiled in four
-# groups (csrc/Makefile)
+# (label, source, extra flags): the instantiations of the 64-column, the split and the wave-pair kernel are one source each, compiled in
+# four groups (csrc/Makefile)
 UNITS = [(f"nmf_fused16_inst{g}", "nmf_fused16_inst", (f"-DNMF_K16_GROUP={g}",)) for g in range(4)] + \
         [(f"nmf_split16_inst{g}", "nmf_split16_inst", (f"-DNMF_S16_GROUP={g}",)) for g in range(4)] + \
+        [(f"nmf_pair16_inst{g}", "nmf_pair16_inst", (f"-DNMF_P16_GROUP={g}",)) for g in range(4)] + \
         [(u, u, ()) for u in ("nmf_fused16", "nmf_pair16", "nmf_split16", "nmf_fused32", "nmf_kernels", "nmf_gemm")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950",
