@@ -35,9 +35,19 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU 
 # kernel from the committed PMC passes of this very command (profiles/pmc_static.json, written by tools/pmc_summary.py --json),
 # reported with its source; dividing it by THIS run's ms_per_launch gives `hbm_tbps` next to `algorithmic_tbps`.
 def pmc_static(M, N, K):
+    """the committed PMC passes of this shape, or None; with "stale": <why> when they were taken of other kernel sources than this
+    tree's (tools/kernel_identity.py) -- `traffic` is then reported as null instead of next to live timings it does not belong to"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_static.json")) as f:
-            return json.load(f).get(f"{M}x{N}x{K}")
+            e = json.load(f).get(f"{M}x{N}x{K}")
+        if e is None:
+            return None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_identity import kernel_sources_sha16
+        have, want = e.get("kernel_sources_sha16"), kernel_sources_sha16()
+        if have != want:
+            e = dict(e, stale=f"the committed PMC passes are of kernel sources {have or 'of an unrecorded build'}, this tree's are {want}: traffic not quoted")
+        return e
     except Exception:
         return None
 
@@ -316,7 +326,7 @@ def main():
     which = "H" if ms_h >= ms_w else "W"
     pmc = pmc_static(M, Nloc, K)
     alg_bytes = algorithmic_bytes(M, Nloc, K)[0 if which == "H" else 1]
-    traffic = pmc["hbm_bytes_per_launch"][which] if pmc else None
+    traffic = pmc["hbm_bytes_per_launch"][which] if (pmc and not pmc.get("stale")) else None
     if shard is not None:
         # torch.distributed path: event pairs on the shard's stream around the all-reduce and around the whole iteration
         ev = []
@@ -376,12 +386,12 @@ def main():
                          # HBM bytes per launch of the dominant kernel: PMC counters of the committed passes of this command
                          # (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), not collected by this run; null where no pass is committed
                          "traffic": traffic,
-                         "traffic_source": pmc["source"] if pmc else None,
+                         "traffic_source": (pmc.get("stale") or pmc["source"]) if pmc else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "hbm_tbps": (traffic / (ms_k * 1e-3) / 1e12) if traffic else None,
                          "algorithmic_tbps": alg_bytes / (ms_k * 1e-3) / 1e12,
-                         "mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"][which] if pmc else None,
+                         "mfma_busy_frac_of_simd_cycles": pmc["mfma_busy_frac_of_simd_cycles"][which] if (pmc and not pmc.get("stale")) else None,
                          "kernel": "%s (%s-step launch, the slower of the two)" % (s.describe(), which),
                          "flop_per_launch": k_flops, "ms_per_launch": ms_k,
                          "ms_h_step": ms_h, "ms_w_step": ms_w,

@@ -107,8 +107,9 @@ typedef struct {
                              *    in [EPS, 2^60] (X checked at upload, W*H per 32-row chunk) -- there they are the identity,
                              *    so the quotient is bit-identical -- and runs the full sequence everywhere else;
                              * -1: always the full sequence (for A/B tests of the above);
-                             * 1: reciprocal refined to <= 1 ulp (one correction step fewer): bit-identical on 3e9 sampled
-                             *    operand pairs but not proven so; differs where x/y overflows or is subnormal */
+                             * 1: accepted and ignored since round 5 (it selected the same six-instruction quotient without the range
+                             *    guard -- bit-identical inside the guard range by exhaustive enumeration, DESIGN.md 4.1c -- and measured
+                             *    0.1 .. 1.9 % slower than the guarded default: profiles/r05_ab_fast_divide.log) */
     int   restart_lanes;    /* update_div_restarts only.  0 = automatic: shapes the split kernel takes (K <= 256 and small enough, see split_kernel)
                              * and shapes of the 64-column kernel whose lone launch leaves CUs idle (K <= 512, N < 32768) run ALL restarts in
                              * every launch (the restart index is a grid dimension); other shapes iterate two initialisations side by side on

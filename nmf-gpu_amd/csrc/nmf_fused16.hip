@@ -11,12 +11,12 @@ namespace nmf {
 NMF_K16_ALL(NMF_K16_EXTERN)
 #undef NMF_K16_EXTERN
 
-// the K the 16-column kernel computes on for a logical K: the next multiple of 16 (every one up to 512 is instantiated), 0 = none
+// the K the 16-column kernel computes on for a logical K: the next multiple of 16 (every one up to kMaxK16 = 576 is instantiated), 0 = none
 int fused16_compute_k(int K) {
-    if (K > 512 || K < 1) return 0;
+    if (K > kMaxK16 || K < 1) return 0;
     return (K + 15) & ~15;
 }
-static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 16 && Kc <= 512 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
+static bool k16_shape_ok(int Kp, int Kc) { return Kc >= 16 && Kc <= kMaxK16 && Kc == fused16_compute_k(Kc) && Kp == ((Kc + 31) & ~31); }
 
 // C(Mp x Np) = A(Mp x Kp) * B(Kp x Np), all contiguous column-major; Mp % 32 == 0, Np % 16 == 0, Kp a multiple of 32 in [64, 512]
 // (the kernel stages whole 32-column pieces of A: no padding inside a caller's matrix to read instead)

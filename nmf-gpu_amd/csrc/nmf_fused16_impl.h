@@ -1,4 +1,4 @@
-// nmf_fused16_impl.h -- the production fused half-step of update_div (cuda/nmf.cu:118-176) for K <= 512:
+// nmf_fused16_impl.h -- the production fused half-step of update_div (cuda/nmf.cu:118-176) for K <= 576:
 // 16 owned columns per wave on v_mfma_f32_16x16x4_f32, and the KL check built from the same code.
 // Included by nmf_fused16.hip (dispatch) and nmf_fused16_inst.hip (the instantiations, compiled in groups).
 #pragma once
@@ -392,7 +392,10 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
     const dim3 grid((unsigned)(((Q + 63) / 64) * a.nsplit), (unsigned)a.batch), block(256);
     const size_t lds = k16_lds_bytes<KT>();
     const bool partial = a.partial != 0;
-    const bool fast = fused_fast_divide() || a.fast_divide;
+    // (nmf_opts.fast_divide = 1 used to select DIV = 1 instantiations -- the six-instruction quotient without the range guard.  Measured in
+    //  round 5 it is 0.1 .. 1.9 % SLOWER than the guarded default on every family (profiles/r05_ab_fast_divide.log: the guard is four
+    //  v_max3 and a ballot, and the unguarded variant lost the packed arrangement of the guarded block), so those instantiations --
+    //  half of all kernels -- are gone and the option is accepted and ignored.)
 #define NMF_LAUNCH_K16(...)                                                                               \
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
@@ -403,34 +406,20 @@ hipError_t launch_fused_k16(const FusedArgs &a, bool wstep, hipStream_t stream) 
     if constexpr (KT <= 16) {   // the variants whose product 1 ends two / three steps early (FusedArgs::p1_trim)
 #define NMF_LAUNCH_K16_TRIM(T)                                                                                                        \
         {                                                                                                                             \
-            if (fast) {                                                                                                               \
-                if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 1, false, OCC, false, T>);             \
-                else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 1, false, OCC, false, T>);          \
-                else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 1, false, OCC, false, T>);          \
-                else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 1, false, OCC, false, T>);                                  \
-            } else {                                                                                                                  \
-                if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 0, false, OCC, false, T>);             \
-                else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 0, false, OCC, false, T>);          \
-                else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 0, false, OCC, false, T>);          \
-                else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 0, false, OCC, false, T>);                                  \
-            }                                                                                                                         \
+            if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 0, false, OCC, false, T>);                 \
+            else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 0, false, OCC, false, T>);              \
+            else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 0, false, OCC, false, T>);              \
+            else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 0, false, OCC, false, T>);                                      \
             return hipGetLastError();                                                                                                 \
         }
         if constexpr (KT > 1) { if (a.p1_trim == 3) NMF_LAUNCH_K16_TRIM(3) }
         if (a.p1_trim >= 2) NMF_LAUNCH_K16_TRIM(2)
 #undef NMF_LAUNCH_K16_TRIM
     }
-    if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 1, false, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 1, false, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 1, false, OCC>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 1, false, OCC>);
-    } else {
-        if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 0, false, OCC>);
-        else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 0, false, OCC>);
-        else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 0, false, OCC>);
-        else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 0, false, OCC>);
-    }
+    if (!wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, false, 0, false, OCC>);
+    else if (!wstep && partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, false, true, 0, false, OCC>);
+    else if (wstep && !partial) NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, false, 0, false, OCC>);
+    else NMF_LAUNCH_K16(fused_step_kernel_k16<KT, true, true, 0, false, OCC>);
 #undef NMF_LAUNCH_K16
     return hipGetLastError();
 }
@@ -465,12 +454,13 @@ hipError_t launch_gemm_k16(const float *A, const float *B, float *C, int Mp, int
     return hipGetLastError();
 }
 
-// Every KT with a kernel: all multiples of 16 from K = 16 to 512, in the four groups
+// Every KT with a kernel: all multiples of 16 from K = 16 to 576 (kMaxK16: round 5 added KT = 33 .. 36 -- 162 KB of the 160 KiB of LDS at
+// K = 576, <= 450 registers -- so that K just above 512 stays on this kernel instead of the wave-pair kernel's 77-80 %), in the four groups
 // nmf_fused16_inst.hip is compiled in (balanced by code size).  X(KT) is applied to each.
-#define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32) X(17)
-#define NMF_K16_GROUP1(X) X(1) X(11) X(12) X(13) X(14) X(30) X(19) X(31)
-#define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28) X(21) X(29)
-#define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26) X(23) X(25) X(27)
+#define NMF_K16_GROUP0(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(32) X(17) X(36)
+#define NMF_K16_GROUP1(X) X(1) X(11) X(12) X(13) X(14) X(30) X(19) X(31) X(35)
+#define NMF_K16_GROUP2(X) X(15) X(16) X(18) X(28) X(21) X(29) X(34)
+#define NMF_K16_GROUP3(X) X(20) X(22) X(24) X(26) X(23) X(25) X(27) X(33)
 #define NMF_K16_ALL(X) NMF_K16_GROUP0(X) NMF_K16_GROUP1(X) NMF_K16_GROUP2(X) NMF_K16_GROUP3(X)
 
 }  // namespace nmf

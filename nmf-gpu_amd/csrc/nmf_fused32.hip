@@ -547,11 +547,6 @@ static hipError_t launch_fused_kt(const FusedArgs &a, bool wstep, hipStream_t st
         else if (!wstep && partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, false, true>);
         else if (wstep && !partial) NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, true, false>);
         else NMF_LAUNCH_FUSED(fused_step_kernel_v1<KT, true, true>);
-    } else if (fused_fast_divide() || a.fast_divide) {
-        if (!wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, false, 1>);
-        else if (!wstep && partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, true, 1>);
-        else if (wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, false, 1>);
-        else NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, true, true, 1>);
     } else {
         if (!wstep && !partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, false, 0>);
         else if (!wstep && partial) NMF_LAUNCH_FUSED3(fused_step_kernel_v3<KT, false, true, 0>);

@@ -111,6 +111,7 @@ struct nmf_solver {
     // split path (nmf_split16_impl.h): four waves per 16 owned columns, normalisers summed in-stream, `batch` (W, H) pairs per launch
     bool split = false;
     int batch = 1;
+    int cus = 256;                 // compute units the launch planning counted (the device's, plan_solver)
     int split_batch = 1;           // restarts in the whole update_div_restarts call this solver serves a share of (>= batch): what pick_split sees
     int ns_h = 1, ns_w = 1;        // workgroup-level splits of the reduction dimension on the split path
     int nw_h = 4, nw_w = 4;        // waves per workgroup of the two half-steps (8 where K = 64 and the reduction length allows)
@@ -173,7 +174,14 @@ struct Arena {
         char *base = nullptr;
         const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;
         const double t0 = now_s();
-        HIPCHK(hipMalloc((void **)&base, total ? total : 256));
+        if (const char *lim = getenv("NMF_FAULT_ARENA_LIMIT_MB")) {   // fault injection for the tests: a device with this much free memory
+            if ((double)total > atof(lim) * 1048576.0) { set_err("a solver of %.1f MiB does not fit the device's free memory (NMF_FAULT_ARENA_LIMIT_MB)", total / 1048576.0); return NMF_ERR_NOMEM; }
+        }
+        {
+            const hipError_t me = hipMalloc((void **)&base, total ? total : 256);
+            if (me == hipErrorOutOfMemory) { (void)hipGetLastError(); set_err("a solver of %.1f GiB does not fit the device's free memory", total / 1073741824.0); return NMF_ERR_NOMEM; }
+            HIPCHK(me);
+        }
         const double t1 = now_s();
         *base_out = base;
         // one 16-byte-store kernel over the whole arena instead of a hipMemsetAsync per zero-initialised buffer (those took 18-21 ms
@@ -222,16 +230,33 @@ void release_stream(hipStream_t st) {
 // launch_apply_w_colsum walks a column of W with one 1024-thread workgroup: fine up to 64 rows per thread
 constexpr int kMaxRowsApplyColsum = 65536;
 
+// The launch planning below (how a half-step's reduction is cut, which kernel family serves a shape) counts compute units.  The number comes
+// from the device the solver is created on (hipDeviceAttributeMultiprocessorCount: 256 on a whole MI355X, fewer on a CPX / NPS partition of
+// one); nmf_plan_describe, which touches no device, plans for 256.  NMF_PLAN_CUS overrides both (tests, A/B).  The fitted constants of the
+// models (occupancy penalties, crossovers in elements per CU) were measured on 256 CUs and are carried over per CU.
+constexpr int kDefaultCus = 256;
+static int plan_cus_override() {
+    const char *e = getenv("NMF_PLAN_CUS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= 4096) ? v : 0;
+}
+static int device_cus() {
+    if (const int o = plan_cus_override()) return o;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); return kDefaultCus; }
+    return n;
+}
+
 // workgroups of the 64-column kernel a CU holds at once, by the registers and the LDS of its instantiations (profiles/r04_kernel_resources.md:
 // K = 16: 90 registers; K <= 64: <= 120; K <= 128: <= 168 and 44 KiB; K <= 256: two by __launch_bounds__; above: one)
 static int k16_resident(int kc) { return kc <= 64 ? 4 : (kc <= 128 ? 3 : (kc <= 256 ? 2 : 1)); }
 
 // The rule of rounds 1-3 (and of the kernels without an occupancy table: the wave-pair and the 32-column kernels): workgroups per
 // split-less launch = batch * ceil(Q/q_per_group); aim for >= 512 workgroups (2 per CU), keep >= 2 chunks of 32 per split.
-static int pick_nsplit_512(int q_extent, int p_extent, int q_per_group, int batch) {
+static int pick_nsplit_512(int q_extent, int p_extent, int q_per_group, int batch, int cus) {
     const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
-    if (nq >= 256) return 1;
-    int ns = (int)((512 + nq - 1) / nq);
+    if (nq >= cus) return 1;
+    int ns = (int)((2L * cus + nq - 1) / nq);
     const int max_ns = (p_extent / 32) / 2 > 0 ? (p_extent / 32) / 2 : 1;
     if (ns > max_ns) ns = max_ns;
     if (ns > 64) ns = 64;
@@ -251,8 +276,8 @@ static int pick_nsplit_512(int q_extent, int p_extent, int q_per_group, int batc
 //   * slabs: 0.4 % + 0.2 % per cut for writing them and for the apply launch that sums them.
 // A launch that carries `batch` pairs (restarts) hands out batch times the workgroups and is planned as such -- with the batch of the
 // whole update_div_restarts call, so that a restart gets the same cuts, hence the same bits, wherever it runs.
-static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch, int resident, int kt) {
-    if (resident < 1 || kt < 1) return pick_nsplit_512(q_extent, p_extent, q_per_group, batch);
+static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch, int resident, int kt, int cus) {
+    if (resident < 1 || kt < 1) return pick_nsplit_512(q_extent, p_extent, q_per_group, batch, cus);
     const long nq = (long)((q_extent + q_per_group - 1) / q_per_group) * (batch > 1 ? batch : 1);
     const int chunks = p_extent / 32 > 0 ? p_extent / 32 : 1;
     int max_ns = chunks / 2 > 0 ? chunks / 2 : 1;
@@ -260,8 +285,8 @@ static int pick_nsplit(int q_extent, int p_extent, int q_per_group, int batch, i
     int best = 1;
     double best_cost = 0.0;
     for (int ns = 1; ns <= max_ns; ++ns) {
-        const long wgs = nq * ns, per_cu = (wgs + 255) / 256;
-        const double balance = (double)(per_cu * 256) / (double)wgs;
+        const long wgs = nq * ns, per_cu = (wgs + cus - 1) / cus;
+        const double balance = (double)(per_cu * cus) / (double)wgs;
         const long r = per_cu < resident ? per_cu : resident;
         const double a = r <= 1 ? 1.0 : (r == 2 ? 0.2 : (r == 3 ? 0.08 : 0.0));
         const double cost = balance * ((kt + a) / kt) * (1.0 + 2.0 * ns / chunks) * (ns > 1 ? 1.004 + 0.002 * ns : 1.0);
@@ -298,16 +323,16 @@ static int create_batched(nmf_solver **out, int M, int N, int K, int batch, cons
 // Which kernel family serves a shape.  The split kernel (four waves per 16 owned columns, normalisers in-stream, no helper
 // launches) wins wherever one workgroup per 64 owned columns leaves CUs idle or needs many partial slabs; the 64-column
 // kernel wins once both half-steps fill the chip on their own (measured crossover: tools/shape_bench.py).
-static int pick_split(int q_valid, int p_extent, int sc_rows, int batch = 1, int wg_per_cu = 1);
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch, int wg_per_cu, int cus);
 // how far a lone problem's split-kernel launch is from filling the chip evenly: CUs idle (fewer workgroups than CUs) or a part of
 // them running a second round (more), as a factor on the launch's time
-static double split_kernel_balance(int q, int p, int wg_per_cu) {
+static double split_kernel_balance(int q, int p, int wg_per_cu, int cus) {
     const int qv = (q + 31) & ~31, tasks = qv / 16;
-    const long wgs = (long)tasks * pick_split(qv, (p + 127) & ~127, 128, 1, wg_per_cu);
-    return wgs <= 256 ? 256.0 / (double)wgs : (double)(((wgs + 255) / 256) * 256) / (double)wgs;
+    const long wgs = (long)tasks * pick_split(qv, (p + 127) & ~127, 128, 1, wg_per_cu, cus);
+    return wgs <= cus ? (double)cus / (double)wgs : (double)(((wgs + cus - 1) / cus) * cus) / (double)wgs;
 }
 static int split_pad_k(int K) { return K <= 256 ? pad32(K) : 0; }   // K in HBM: padded to 32 like the reference; the kernel computes on split_compute_k(K)
-static bool want_split(int M, int N, int K, const nmf_opts &o) {
+static bool want_split(int M, int N, int K, const nmf_opts &o, int cus) {
     const int kp = split_pad_k(K);
     if (!kp || !split_step_supports(kp) || o.split_kernel < 0 || o.path == NMF_PATH_UNFUSED) return false;
     if (((size_t)M + 127) * kp >= ((size_t)1 << 30) || ((size_t)N + 127) * kp >= ((size_t)1 << 30)) return false;
@@ -322,12 +347,13 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
     // per workgroup and at most 256 workgroups: 157 or 314 of them (N = 2500, 5000) leave a third of the CUs idle or waiting for a second
     // round, where the 64-column kernel cuts its reduction to fit (3000 x 5000 x 100: 198 us against 140).
     const int kc = split_compute_k(K);
-    const size_t mn = (size_t)M * (size_t)N;
-    const size_t lim = K <= 16 ? ((size_t)1 << 23) : (kc <= 112 ? ((size_t)3 << 22) : (kc <= 128 ? ((size_t)1 << 23) : ((size_t)1 << 21)));
+    // (the fits are of a 256-CU chip and carried over per CU: `unit` = 2^21 elements on 256 CUs, 2^13 per CU)
+    const size_t mn = (size_t)M * (size_t)N, unit = (((size_t)1 << 21) * (size_t)cus) / 256;
+    const size_t lim = K <= 16 ? 4 * unit : (kc <= 112 ? 6 * unit : (kc <= 128 ? 4 * unit : unit));
     if (mn > lim) return false;
-    if (mn >= ((size_t)1 << 22)) {
+    if (mn >= 2 * unit) {
         const int wpc = kp <= 64 ? 2 : 1;
-        const double bh = split_kernel_balance(N, M, wpc), bw = split_kernel_balance(M, N, wpc);
+        const double bh = split_kernel_balance(N, M, wpc, cus), bw = split_kernel_balance(M, N, wpc, cus);
         if ((bh > bw ? bh : bw) >= 1.3) return false;
     }
     return true;
@@ -344,15 +370,15 @@ static bool want_split(int M, int N, int K, const nmf_opts &o) {
 // are preferred (32 superchunks three ways -- 11, 11, 10 -- cost 99 us where four ways cost 88).  `batch` is the restart count
 // of the whole update_div_restarts call (not of one device's or one chunk's share), so that a restart gets the same split --
 // hence the same bits -- wherever it runs.
-static int pick_split(int q_valid, int p_extent, int sc_rows, int batch, int wg_per_cu) {
+static int pick_split(int q_valid, int p_extent, int sc_rows, int batch, int wg_per_cu, int cus) {
     const int tasks = q_valid / 16, nsc = p_extent / sc_rows;
     if (nsc <= 1) return 1;
     int S;
     if (batch <= 1) {
-        if (tasks >= 192) return 1;
-        S = 256 / tasks;
+        if (4 * tasks >= 3 * cus) return 1;   // three quarters of the CUs busy: a second slab costs more than the idle quarter
+        S = cus / tasks;
     } else {
-        const long groups = (long)tasks * batch, target = 256L * (wg_per_cu > 1 ? 2 : 1);
+        const long groups = (long)tasks * batch, target = (long)cus * (wg_per_cu > 1 ? 2 : 1);
         if (groups >= target) return 1;
         S = (int)((target + groups - 1) / groups);
         for (int d = S; d <= 2 * S && d <= nsc; ++d) if (nsc % d == 0) { S = d; break; }   // an even division if one is near
@@ -365,17 +391,18 @@ static int pick_split(int q_valid, int p_extent, int sc_rows, int batch, int wg_
 
 // Everything about a solver that follows from the shape and the options alone -- kernel family, padded dims, split counts,
 // waves per workgroup: no HIP call in here, so the decision tables can be tested on a machine without a GPU (nmf_plan_describe)
-static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, int batch, int split_batch) {
+static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, int batch, int split_batch, int cus) {
     s->M = M; s->N = N; s->K = K;
     int path = o.path;
     s->batch = batch;
-    s->split = want_split(M, N, K, o);
+    s->cus = cus;
+    s->split = want_split(M, N, K, o, cus);
     // the split kernel streams whole superchunks of 128: zero padding is invariant under the updates and adds nothing to any sum
     s->Mp = s->split ? ((M + 127) & ~127) : pad32(M);
     s->Np = s->split ? ((N + 127) & ~127) : pad32(N);
     if (s->split) path = NMF_PATH_FUSED;
     // the 16x16x4 kernels address the streamed factor with 32-bit lane offsets and have no 64-bit fallback
-    const bool k16_too_tall = fused_pad_k(K) >= 32 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > 512 ? 30 : 31));
+    const bool k16_too_tall = fused_pad_k(K) >= 32 && (size_t)fused_pad_k(K) * (size_t)s->Mp >= ((size_t)1 << (fused_pad_k(K) > kMaxK16 ? 30 : 31));
     if (path == NMF_PATH_AUTO) path = (fused_pad_k(K) && !k16_too_tall) ? NMF_PATH_FUSED : NMF_PATH_UNFUSED;
     if (path == NMF_PATH_FUSED && k16_too_tall) { set_err("fused path supports M*K < 2^31"); return NMF_ERR_UNSUPPORTED; }
     if (path == NMF_PATH_FUSED) {
@@ -399,7 +426,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
     // a batch of (W, H) pairs per launch: the split kernel, or the 64-column kernel where its W-step delivers the row sums of H
     // (blockIdx.y = pair: nmf_fused16_impl.h); the 32-column and the wave-pair kernels and the operator path take one pair
     if (batch > 1 && !s->split && !(path == NMF_PATH_FUSED && fused_takes_batch(s->Kp) && s->Mp <= kMaxRowsApplyColsum)) {
-        set_err("batched solvers need the split kernel or the 64-column kernel (K <= 512, M <= 65536)");
+        set_err("batched solvers need the split kernel or the 64-column kernel (K <= 576, M <= 65536)");
         return NMF_ERR_UNSUPPORTED;
     }
     s->use_graph = o.use_graph > 0 ? 1 : 0;   // 0: eager + per-piece timers in update_div_ex; < 0: eager, untimed
@@ -415,8 +442,8 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call (pick_split)
         s->split_batch = sb;
         const int wpc = (s->Kp <= 64 || (s->Kp <= 128 && sb > 1)) ? 2 : 1;   // workgroups the LDS image lets share a CU (split_args: single_image)
-        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb, wpc);
-        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb, wpc);
+        s->ns_h = o.nsplit_h > 0 ? o.nsplit_h : pick_split((N + 31) & ~31, s->Mp, 32 * s->nw_h, sb, wpc, cus);
+        s->ns_w = o.nsplit_w > 0 ? o.nsplit_w : pick_split((M + 31) & ~31, s->Np, 32 * s->nw_w, sb, wpc, cus);
         const int nsc_h = s->Mp / (32 * s->nw_h), nsc_w = s->Np / (32 * s->nw_w);
         if (s->ns_h > nsc_h) s->ns_h = nsc_h;
         if (s->ns_w > nsc_w) s->ns_w = nsc_w;
@@ -427,11 +454,11 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         const int sb = split_batch > 0 ? split_batch : batch;   // restarts in the whole call: a restart gets the same splits wherever it runs
         s->split_batch = sb;
         const char *rese = getenv("NMF_NSPLIT_RESIDENT");   // A/B: 0 = the 512-workgroup rule of rounds 1-3 whatever the K
-        // the wave-pair kernel (K > 512) holds one workgroup per CU: the same model with r = 1 (balance and fixed work decide; 3000 x 20000 x 700
+        // the wave-pair kernel (K > 576) holds one workgroup per CU: the same model with r = 1 (balance and fixed work decide; 3000 x 20000 x 700
         // 3.69 -> 2.99 ms per iteration, 3000 x 3000 x 1000 0.88 -> 0.71: profiles/r04_nsplit_model.log)
-        const int res = rese ? atoi(rese) : (s->Kp > 512 ? 1 : (!getenv("NMF_FUSED_VARIANT") ? k16_resident(s->Kc) : 0));
-        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res, s->Kc / 16);
-        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res, s->Kc / 16);
+        const int res = rese ? atoi(rese) : (s->Kp > kMaxK16 ? 1 : (!getenv("NMF_FUSED_VARIANT") ? k16_resident(s->Kc) : 0));
+        s->nsplit_h = o.nsplit_h > 0 ? o.nsplit_h : pick_nsplit(s->Np, s->Mp, qg, sb, res, s->Kc / 16, cus);
+        s->nsplit_w = o.nsplit_w > 0 ? o.nsplit_w : pick_nsplit(s->Mp, s->Np, qg, sb, res, s->Kc / 16, cus);
         if (s->nsplit_h > s->Mp / 32) s->nsplit_h = s->Mp / 32;
         if (s->nsplit_w > s->Np / 32) s->nsplit_w = s->Np / 32;
         s->chk_groups = check_num_groups(s->Np, s->Kp);
@@ -443,7 +470,7 @@ static int plan_solver(nmf_solver *s, int M, int N, int K, const nmf_opts &o, in
         // The KL check is an H-step-shaped launch (product 1 only) on the 64-column kernel whichever family iterates: six workgroups for the
         // reference's 350 columns -- 183 us, six iterations' worth, +30 % on a run that checks every 25 iterations.  Its reduction over M is cut
         // by the same model as a half-step's, always as for a lone problem: a restart's KL has the same bits alone and in a batch.
-        s->ns_chk = pick_nsplit(s->Np, s->Mp, 64, 1, k16_resident(s->Kc), s->Kc / 16);
+        s->ns_chk = pick_nsplit(s->Np, s->Mp, 64, 1, k16_resident(s->Kc), s->Kc / 16, cus);
         if (s->ns_chk > s->Mp / 32) s->ns_chk = s->Mp / 32 > 0 ? s->Mp / 32 : 1;
         s->chk_groups = check_num_groups(s->Np, s->Kp) * s->ns_chk;
     }
@@ -457,13 +484,14 @@ extern "C" int nmf_plan_describe(int M, int N, int K, int batch, const nmf_opts 
     nmf_opts o;
     if (opts_in) o = *opts_in; else nmf_default_opts(&o);
     nmf_solver s;
-    NMFCHK(plan_solver(&s, M, N, K, o, batch, 0));
+    const int cus = plan_cus_override() ? plan_cus_override() : kDefaultCus;   // no device is touched here
+    NMFCHK(plan_solver(&s, M, N, K, o, batch, 0, cus));
     return nmf_solver_describe(&s, buf, buflen);
 }
 
 static int solver_init(nmf_solver *s, int M, int N, int K, const nmf_opts &o, const nmf_solver *x_from, int batch, int split_batch) {
     const double t0 = now_s();
-    NMFCHK(plan_solver(s, M, N, K, o, batch, split_batch));
+    NMFCHK(plan_solver(s, M, N, K, o, batch, split_batch, device_cus()));
     const int path = s->path;
     s->comm = (nmf_comm *)o.comm;
     if (s->comm) s->block_budget_s = nmf_comm_timeout_s();   // waits outside solver_run (a check after iterate()) carry the communicator's deadline too
@@ -561,10 +589,14 @@ extern "C" int nmf_solver_describe(const nmf_solver *s, char *buf, int buflen) {
     if (!s || !buf || buflen <= 0) return NMF_ERR_ARG;
     if (s->path != NMF_PATH_FUSED) snprintf(buf, (size_t)buflen, "unfused operators (gemm_kernel), Mp=%d Np=%d Kp=%d", s->Mp, s->Np, s->Kp);
     else if (s->split) snprintf(buf, (size_t)buflen, "split_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d splits(h,w)=(%d,%d) batch=%d", s->Kc / 16, s->Mp, s->Np, s->Kp, s->ns_h, s->ns_w, s->batch);
-    else if (s->Kp > 512) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<KTH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kc / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    else if (s->Kp > kMaxK16) snprintf(buf, (size_t)buflen, "fused_step_kernel_pair<KTH=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kc / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
     else if (!getenv("NMF_FUSED_VARIANT")) snprintf(buf, (size_t)buflen, "fused_step_kernel_k16<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)%s", s->Kc / 16, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w,
                                                                s->p1_trim == 3 ? " p1_trim=3" : (s->p1_trim == 2 ? " p1_trim=2" : ""));
     else snprintf(buf, (size_t)buflen, "fused_step_kernel_v3<KT=%d> Mp=%d Np=%d Kp=%d nsplit(h,w)=(%d,%d)", s->Kp / 32, s->Mp, s->Np, s->Kp, s->nsplit_h, s->nsplit_w);
+    if (s->cus != kDefaultCus) {   // planned for a chip (partition) with another CU count: say so
+        const size_t n = strlen(buf);
+        if (n + 12 < (size_t)buflen) snprintf(buf + n, (size_t)buflen - n, " cus=%d", s->cus);
+    }
     return NMF_OK;
 }
 extern "C" void *nmf_solver_stream(nmf_solver *s) { return s ? (void *)s->stream : nullptr; }
@@ -1583,7 +1615,7 @@ static int auto_lanes(const nmf_solver *s, int n_restarts) {
 // it would -- same kernels, same split counts, hence the same bits -- and freezing at its own convergence check.
 constexpr int kMaxRestartBatch = 64;
 static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o_in, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
-    const int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
+    int B = n_restarts < kMaxRestartBatch ? n_restarts : kMaxRestartBatch;
     nmf_opts o = o_in;
     // as in update_div_ex: a run this short does not earn back the capture and instantiation of its graphs (every launch of a
     // batch outlasts its own enqueue by far): 16 restarts x 200 iterations, whole call, eager / captured: cfg2 69.5-70.3 /
@@ -1592,8 +1624,18 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
     const bool trace = getenv("NMF_RESTART_TRACE") != nullptr;   // wall time of every phase of the call, to stderr
     double tp = now_s();
     auto phase = [&](const char *what) { if (trace) { const double t = now_s(); fprintf(stderr, "nmf restarts: %-28s %8.3f ms\n", what, (t - tp) * 1e3); tp = t; } };
+    // A batched solver holds B copies of W, H and of the slabs behind ONE X (65536 x 512 with 64 pairs: > 8 GB of slabs per cut).  Where
+    // the device cannot hold B pairs the call makes more passes with fewer: the cuts -- hence every restart's bits -- follow split_batch,
+    // the restart count of the whole call, not the number of pairs one solver carries (as with the 64-pair limit and with worker shares).
     nmf_solver *s = nullptr;
-    NMFCHK(create_batched(&s, M, N, K, B, &o, split_batch));
+    for (;;) {
+        const int cst = create_batched(&s, M, N, K, B, &o, split_batch);
+        if (cst == NMF_OK) break;
+        if (cst != NMF_ERR_NOMEM || B == 1) return cst;
+        (void)hipGetLastError();
+        B = (B + 1) / 2;
+        if (trace) fprintf(stderr, "nmf restarts: not enough device memory for the batch; retrying with %d pairs per pass\n", B);
+    }
     phase("solver (allocation)");
     int st = X.mat ? nmf_solver_upload(s, nullptr, nullptr, X.mat) : nmf_solver_upload_device(s, nullptr, nullptr, X.mat_d);
     phase("X upload");
@@ -1655,19 +1697,19 @@ static int restarts_batched(const matrix *W, const matrix *H, int n_restarts, ma
 // always.  Shapes of the 64-column kernel: where a lone pair's launch leaves CUs idle or needs partial slabs to fill them --
 // fewer than 512 column groups in the H-step (N < 32768) -- e.g. 4096 x 4096 x 256, 2048 x 8192 x 512; above that one launch
 // fills the chip by itself and the restarts run one after the other (auto_lanes).
-static bool restarts_take_batch(int M, int N, int K, const nmf_opts &o) {
-    if (want_split(M, N, K, o)) return true;
+static bool restarts_take_batch(int M, int N, int K, const nmf_opts &o, int cus) {
+    if (want_split(M, N, K, o, cus)) return true;
     if (o.path == NMF_PATH_UNFUSED || o.split_kernel > 0) return false;
     const int kp = fused_pad_k(K), Mp = pad32(M), Np = pad32(N);
     if (!kp || !fused_takes_batch(kp) || Mp > kMaxRowsApplyColsum || (size_t)kp * (size_t)Mp >= ((size_t)1 << 31)) return false;
-    return (Np + 63) / 64 < 512;
+    return (Np + 63) / 64 < 2 * cus;
 }
 
 // all restarts of `W`, `H` on ONE device (o.device, or the current one); split_batch: restart count of the whole call
 static int restarts_one_device(const matrix *W, const matrix *H, int n_restarts, matrix X, const nmf_opts &o, int M, int N, int K, int *best, double *kl, int split_batch, const int *gidx = nullptr) {
     if (o.device >= 0) HIPCHK(hipSetDevice(o.device));
     // restart_lanes > 0 asks for the stream-lane mechanism explicitly (the shapes no batched kernel takes use it anyway)
-    const bool batched = o.restart_lanes <= 0 && !o.comm && restarts_take_batch(M, N, K, o);
+    const bool batched = o.restart_lanes <= 0 && !o.comm && restarts_take_batch(M, N, K, o, device_cus());
     if (n_restarts > 1 && batched) return restarts_batched(W, H, n_restarts, X, o, M, N, K, best, kl, split_batch, gidx);
     if (n_restarts == 1 && split_batch > 1 && batched)   // this device's share of a batched call
         return restarts_batched(W, H, 1, X, o, M, N, K, best, kl, split_batch, gidx);

@@ -10,7 +10,8 @@ namespace nmf {
 
 constexpr float kEps = (float)(2.2204E-16);   // cuda/matrix.cu:10
 constexpr int kPad = 32;                      // device buffers are padded to multiples of 32 (cf. PAD_MULT, cuda/matrix.cuh:7)
-constexpr int kMaxFusedK = 1024;               // fused path: K <= 1024 (32x32x2 kernel: K <= 32; 16x16x4 kernel: K <= 512; wave pairs above)
+constexpr int kMaxFusedK = 1024;               // fused path: K <= 1024 (64-column kernel: K <= kMaxK16; wave pairs above)
+constexpr int kMaxK16 = 576;                   // the 64-column kernel's largest K: two 32-row LDS images of it + the X patches = 162 KB of 160 KiB
 
 inline int pad32(int v) { return (v + 31) & ~31; }
 
@@ -38,7 +39,7 @@ struct FusedArgs {
                               //    only (the caller's K <= Kc - 8 / Kc - 12): launch the variant whose chain ends that early (TRIM); 0 = the full chain
     int nsplit;
     int partial;              // 1: write raw partial products (required when nsplit > 1); 0: update U_out in place
-    int fast_divide;          // 1: refined-reciprocal quotient (<= 1 ulp) instead of the correctly rounded one
+    int fast_divide;          // unused since round 5 (the DIV = 1 instantiations are gone: nmf_fused16_impl.h, launch_fused_k16)
     int x_in_range;           // 1: every entry of X is 0 or in [EPS, 2^60] (checked at upload): the 16-column kernel may
                               //    drop the range scaling of IEEE division while the denominators stay <= 2^60 too
     // blockIdx.y = pair of a batched solver (16-column kernel only): W, H of pair b at + b * strideW / strideH floats; its slabs
@@ -67,7 +68,7 @@ bool       gemm_nn16_eligible(int m, int n, int k, long lda, long ldb, long ldc)
 hipError_t launch_gemm_nn16(const float *A, const float *B, float *C, int Mp, int Np, int Kp, hipStream_t stream);
 hipError_t launch_check16(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, int Kc, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0, int nsplit = 1);
-int        fused16_compute_k(int K);   // the multiple of 16 the 16-column kernel computes on for K <= 512, else 0
+int        fused16_compute_k(int K);   // the multiple of 16 the 16-column kernel computes on for K <= kMaxK16, else 0
 hipError_t launch_check32(const float *W, const float *H, const float *X, int Mp, int Np, int Kp, double *part, hipStream_t stream,
                           int batch = 1, size_t strideW = 0, size_t strideH = 0);
 #ifdef NMF_DIAGNOSTICS   // diagnostic build only (make DIAG=1): not in the shipped library
@@ -141,7 +142,7 @@ int        check_num_groups(int Np, int Kp);
 bool       fused_streams_vsum(int Mp, int Kp);   // can the W-step kernel produce FusedArgs::vsum_part for this shape?
 bool       fused_takes_batch(int Kp);   // can a batched solver run this K on the 16-column kernel (blockIdx.y = pair)?
 int        fused_cols_per_group(int Kp);   // owned columns per workgroup of the fused kernels (128, or 64 above K = 256)
-int        fused_pad_k(int K);             // K as the fused path pads it in HBM (a multiple of 32; of 128 above 512), 0 if the fused path cannot take it
+int        fused_pad_k(int K);             // K as the fused path pads it in HBM (a multiple of 32; of 64 above kMaxK16), 0 if the fused path cannot take it
 int        fused_compute_k(int K);         // K as the chosen fused kernel computes on it (FusedArgs::Kc): <= fused_pad_k(K), a multiple of 16
 // batch > 1: `batch` (W, H) pairs, strideW / strideH floats apart, in one launch (grid.y); pair b's check_num_groups triples
 // at part + 3 * check_num_groups * b.  Kp <= 512 (the batched solvers' range); the wave-pair kernel takes one pair at a time.

@@ -29,7 +29,7 @@ namespace nmf {
 
 // which kernel family serves a padded K: the 16-column kernel up to 512 (two workgroups per CU up to 256, one above; K <= 32 too since
 // round 4: 98.5 against 91.1 TFLOP/s at 4096 x 65536 x 32), the 32-column v3 only when NMF_FUSED_VARIANT asks for it (K <= 256)
-static bool use_pair(int Kp) { return Kp > 512; }   // two waves per 16 owned columns, K split between them (nmf_pair16.hip)
+static bool use_pair(int Kp) { return Kp > kMaxK16; }   // two waves per 16 owned columns, K split between them (nmf_pair16.hip)
 static bool use_k16(int Kp) { return !use_pair(Kp) && (Kp > 256 || fused_variant() == 0); }
 
 __global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
@@ -69,14 +69,14 @@ hipError_t launch_check(const float *W, const float *H, const float *X, int Mp, 
 bool fused_streams_vsum(int Mp, int Kp) { return use_k16(Kp) && (size_t)((Mp + 63) / 64) * 8 >= (size_t)Kp; }
 bool fused_takes_batch(int Kp) { return use_k16(Kp); }
 int fused_cols_per_group(int Kp) { return use_pair(Kp) ? 32 : (use_k16(Kp) ? 64 : 128); }
-// K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 512 -- the 16-column kernel has an
-// instantiation for every multiple of 16 up to 512 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
+// K in HBM: padded to 32 like the reference (PAD_MULT, cuda/matrix.cuh:7), nothing coarser up to 576 -- the 16-column kernel has an
+// instantiation for every multiple of 16 up to 576 (fused16_compute_k).  The 32-column kernel (NMF_FUSED_VARIANT=3,
 // an A/B switch) only exists for 32 / 64 / 128 / 256.  0 = not supported.
 int fused_pad_k(int K) {
     const int k32 = pad32(K);
     if (k32 <= 32) return 32;
     if (k32 <= 256 && fused_variant() != 0) { int kt = k32 / 32, p = 1; while (p < kt) p <<= 1; return 32 * p; }
-    if (k32 <= 512) return k32;
+    if (k32 <= kMaxK16) return k32;
     return K <= kMaxFusedK ? pair_pad_k(K) : 0;   // the wave-pair kernel: 64 in HBM (whole staged pieces), 32 in its MFMAs (pair_compute_k)
 }
 int fused_compute_k(int K) {

@@ -1,5 +1,5 @@
 // nmf_pair16.hip -- dispatch of the wave-pair fused half-step (nmf_pair16_impl.h) over its K = 32 KTH instantiations
-// (nmf_pair16_inst.hip): half-steps and the KL check for 512 < K <= 1024.
+// (nmf_pair16_inst.hip): half-steps and the KL check for 576 < K <= 1024.
 #include "nmf_pair16_impl.h"
 
 namespace nmf {
@@ -10,11 +10,11 @@ namespace nmf {
 NMF_P16_ALL(NMF_P16_EXTERN)
 #undef NMF_P16_EXTERN
 
-// the K the wave-pair kernel computes on for a logical K in (512, 1024]: the next multiple of 32 (the reference's PAD_MULT,
+// the K the wave-pair kernel computes on for a logical K in (576, 1024]: the next multiple of 32 (the reference's PAD_MULT,
 // cuda/matrix.cuh:7); the factors are 64-padded in HBM (pair_pad_k): the staging moves whole 64-column pieces.  0 = none
-int pair_compute_k(int K) { return (K > 512 && K <= 1024) ? ((K + 31) & ~31) : 0; }
-int pair_pad_k(int K) { return (K > 512 && K <= 1024) ? ((K + 63) & ~63) : 0; }
-static bool pair_shape_ok(int Kp, int Kc) { return Kc > 512 && Kc <= 1024 && Kc % 32 == 0 && Kp == ((Kc + 63) & ~63); }
+int pair_compute_k(int K) { return (K > kMaxK16 && K <= 1024) ? ((K + 31) & ~31) : 0; }
+int pair_pad_k(int K) { return (K > kMaxK16 && K <= 1024) ? ((K + 63) & ~63) : 0; }
+static bool pair_shape_ok(int Kp, int Kc) { return Kc > kMaxK16 && Kc <= 1024 && Kc % 32 == 0 && Kp == ((Kc + 63) & ~63); }
 
 hipError_t launch_fused_pair(const FusedArgs &a, bool wstep, hipStream_t stream) {
     const int kc = a.Kc > 0 ? a.Kc : a.Kp;

@@ -13,8 +13,8 @@
 // can be double-buffered: 2 x 68 KiB at K = 1024.  The X tile (16 x 16) is loaded straight into the accumulator layout.
 // CHECK = true: the KL / rel-L1 check for this K range (product 1 + exchange, terms summed by the h = 0 wave of each pair).
 //
-// Round 5: the template parameter is KTH = 16 x 16 accumulator tiles per wave, K = 32 KTH for KTH = 17 ... 32 (K = 544, 576, ...,
-// 1024) -- until then NBH = whole 64-blocks per wave, K = 640 / 768 / 896 / 1024 only, and K = 520 computed on 640.  A wave's half
+// Round 5: the template parameter is KTH = 16 x 16 accumulator tiles per wave, K = 32 KTH for KTH = 19 ... 32 (K = 608, 640, ...,
+// 1024; K <= 576 stays on the 64-column kernel) -- until then NBH = whole 64-blocks per wave, K = 640 / 768 / 896 / 1024 only, and K = 520 computed on 640.  A wave's half
 // KH = 16 KTH of K is walked by product 1 in whole blocks of 64 (per-lane runs of 16) and, where KH % 64 != 0, one remainder block in
 // runs of R = KH % 64 / 4 per lane group (k16_kconst / k16_rem_lane, nmf_device.h: the map of the 64-column kernel).  In HBM and in
 // LDS the factors are KP = K rounded up to 64 wide (the staging moves whole 64-column pieces; rows K .. KP - 1 are zero padding no
@@ -335,7 +335,7 @@ hipError_t launch_pair_kth(const FusedArgs &a, bool wstep, hipStream_t stream) {
     const dim3 grid((unsigned)((Q / 32) * a.nsplit)), block(256);
     const size_t lds = pair_lds_bytes(a.Kp);
     const bool partial = a.partial != 0;
-    const bool fast = fused_fast_divide() || a.fast_divide;
+    // (no DIV = 1 instantiations since round 5: nmf_fused16_impl.h, launch_fused_k16)
 #define NMF_LAUNCH_P16(...)                                                                               \
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
@@ -343,17 +343,10 @@ hipError_t launch_pair_kth(const FusedArgs &a, bool wstep, hipStream_t stream) {
         note_kernel((const void *)__VA_ARGS__, stream);                                                   \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a, (double *)nullptr);                \
     } while (0)
-    if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, false, 1>);
-        else if (!wstep && partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, true, 1>);
-        else if (wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, false, 1>);
-        else NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, true, 1>);
-    } else {
-        if (!wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, false, 0>);
-        else if (!wstep && partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, true, 0>);
-        else if (wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, false, 0>);
-        else NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, true, 0>);
-    }
+    if (!wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, false, 0>);
+    else if (!wstep && partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, false, true, 0>);
+    else if (wstep && !partial) NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, false, 0>);
+    else NMF_LAUNCH_P16(fused_step_kernel_pair<KTH, true, true, 0>);
 #undef NMF_LAUNCH_P16
     return hipGetLastError();
 }
@@ -371,9 +364,9 @@ hipError_t launch_check_kth(const float *W, const float *H, const float *X, int 
     return hipGetLastError();
 }
 
-// KTH = K / 32 for every K the family serves (544 ... 1024), in four groups of about equal compile time (the groups build side by side)
-#define NMF_P16_GROUP0(X) X(32) X(21) X(20) X(17)
-#define NMF_P16_GROUP1(X) X(31) X(28) X(23) X(18)
+// KTH = K / 32 for every K the family serves (608 ... 1024: K <= 576 stays on the 64-column kernel), in four groups of about equal compile time (the groups build side by side)
+#define NMF_P16_GROUP0(X) X(32) X(21) X(20)
+#define NMF_P16_GROUP1(X) X(31) X(28) X(23)
 #define NMF_P16_GROUP2(X) X(30) X(27) X(24) X(19)
 #define NMF_P16_GROUP3(X) X(29) X(26) X(25) X(22)
 #define NMF_P16_ALL(X) NMF_P16_GROUP0(X) NMF_P16_GROUP1(X) NMF_P16_GROUP2(X) NMF_P16_GROUP3(X)

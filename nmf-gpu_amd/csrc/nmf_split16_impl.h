@@ -438,7 +438,7 @@ hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t stream) 
     const dim3 grid((unsigned)((Q / 16) * a.nsplit), (unsigned)a.batch), block(64 * NW);
     const size_t lds = ((size_t)(DB ? 2 : 1) * NW * 32 * ((KT + 1) / 2) * kLdv + NW * kXs16Floats) * sizeof(float);
     const bool partial = a.nsplit > 1 || a.force_partial;
-    const bool fast = fused_fast_divide() || a.fast_divide;
+    // (no DIV = 1 instantiations since round 5: nmf_fused16_impl.h, launch_fused_k16)
 #define NMF_LAUNCH_S16(...)                                                                               \
     do {                                                                                                  \
         hipError_t e = ensure_dynamic_lds((const void *)__VA_ARGS__, lds);                                \
@@ -446,17 +446,10 @@ hipError_t launch_split_k16(const SplitArgs &a, bool wstep, hipStream_t stream) 
         note_kernel((const void *)__VA_ARGS__, stream); \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds, stream, a);                                   \
     } while (0)
-    if (fast) {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, false, 1, OCC, DB>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, true, 1, OCC, DB>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, false, 1, OCC, DB>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, true, 1, OCC, DB>);
-    } else {
-        if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, false, 0, OCC, DB>);
-        else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, true, 0, OCC, DB>);
-        else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, false, 0, OCC, DB>);
-        else NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, true, 0, OCC, DB>);
-    }
+    if (!wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, false, 0, OCC, DB>);
+    else if (!wstep && partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, false, true, 0, OCC, DB>);
+    else if (wstep && !partial) NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, false, 0, OCC, DB>);
+    else NMF_LAUNCH_S16(split_step_kernel_k16<KT, NW, true, true, 0, OCC, DB>);
 #undef NMF_LAUNCH_S16
     return hipGetLastError();
 }

@@ -225,6 +225,29 @@ def test_more_restarts_than_one_batch_holds(ng, oracle):
     assert b2 == b1 and kl2 == kl1 and all(np.array_equal(a.mat, b.mat) for a, b in zip(W1 + H1, W2 + H2))
 
 
+def test_a_batch_that_does_not_fit_the_device_is_run_in_more_passes(ng, oracle):
+    """round-4 ADVICE: a batched solver holds B copies of W, H and the slabs; where the device cannot hold them the call used to fail.
+    With the arena capped (NMF_FAULT_ARENA_LIMIT_MB: 12 pairs of 512 x 1024 x 64 do not fit, 6 do) the call halves the pairs per
+    pass; the cuts follow the restart count of the whole call, so every restart comes out bit for bit as in the unrestricted call."""
+    M, N, K, R = 512, 1024, 64, 12
+    X, _, _ = oracle.gen_problem(M, N, K, seed=51)
+    Ws, Hs = _pairs(M, N, K, R, 52)
+    W1, H1 = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+    b1, kl1 = ng.update_div_restarts(W1, H1, ng.Matrix(X), max_iter=40, n_devices=1)
+    pair_mb = 4.0 * (M * K + K * N) / 1048576.0
+    os.environ["NMF_FAULT_ARENA_LIMIT_MB"] = str(4.0 * M * N / 1048576.0 + 9 * pair_mb)     # X + room for nine pairs' factors at most
+    try:
+        W2, H2 = [ng.Matrix(w.copy(order="F")) for w in Ws], [ng.Matrix(h.copy(order="F")) for h in Hs]
+        b2, kl2 = ng.update_div_restarts(W2, H2, ng.Matrix(X), max_iter=40, n_devices=1)
+        os.environ["NMF_FAULT_ARENA_LIMIT_MB"] = "0.001"                                        # not even one pair: the error is named
+        with pytest.raises(ng.NmfError) as e:
+            ng.update_div_restarts(W2, H2, ng.Matrix(X), max_iter=2, n_devices=1)
+        assert "does not fit" in str(e.value)
+    finally:
+        os.environ.pop("NMF_FAULT_ARENA_LIMIT_MB", None)
+    assert b2 == b1 and kl2 == kl1 and all(np.array_equal(a.mat, b.mat) for a, b in zip(W1 + H1, W2 + H2))
+
+
 def test_restart_workers_refuse_what_they_cannot_do(ng, oracle):
     M, N, K = 128, 256, 32
     X, _, _ = oracle.gen_problem(M, N, K, seed=43)

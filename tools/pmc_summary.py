@@ -70,7 +70,11 @@ def half_step(k):
 
 
 if "json" in opt:
-    entry = {"source": opt.get("source", "rocprofv3 --pmc passes (tools/pmc_summary.py)"), "hbm_bytes_per_launch": {}, "mfma_busy_frac_of_simd_cycles": {}, "kernel": {}}
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kernel_identity import kernel_sources_sha16
+    # the passes are of the build in this tree: bench.py quotes them only while the kernel sources are the same (tools/kernel_identity.py)
+    entry = {"source": opt.get("source", "rocprofv3 --pmc passes (tools/pmc_summary.py)"), "hbm_bytes_per_launch": {}, "mfma_busy_frac_of_simd_cycles": {}, "kernel": {},
+             "kernel_sources_sha16": kernel_sources_sha16()}
     for k in sorted(ks):
         hw, c = half_step(k), val[k]
         if hw and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
