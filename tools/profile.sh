@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates what profiles/rNN_* holds: the bench line, its rocprofv3 kernel-trace stats, the PMC passes of the same command,
 # small-shape bench lines + timelines, the batched-restart numbers, the true-K shape sweep.
-#   gpurun -- 'ROUND=r04 bash tools/profile.sh [stage ...]'      (output under gpurun_out/$ROUND_profile; copy what is to be kept to profiles/)
+#   gpurun -- 'ROUND=r05 bash tools/profile.sh [stage ...]'      (output under gpurun_out/$ROUND_profile; copy what is to be kept to profiles/)
 cd /root/repo
 export TMPDIR=/tmp
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 out=gpurun_out/${ROUND}_profile
 mkdir -p $out
 stages=${@:-bench kstats pmc small restarts shapes}
@@ -37,6 +37,6 @@ restarts)
   timeout -k 10 200 python3 tools/restart_split_sweep.py > $out/restart_sweep.log 2>&1; grep "whole call\|nsplit_h=0 nsplit_w=0" $out/restart_sweep.log ;;
 shapes)
   timeout -k 10 600 python3 tools/shape_bench.py 4096x65536x48 4096x65536x64 4096x65536x96 4096x65536x100 4096x65536x128 4096x65536x160 4096x65536x192 4096x65536x200 4096x65536x224 4096x65536x256 \
-      4096x65536x300 8192x16384x512 4096x65536x640 4096x65536x1024 4096x262144x256 > $out/shape_bench.log 2>&1; cat $out/shape_bench.log ;;
+      4096x65536x300 8192x16384x512 4096x65536x544 4096x65536x576 4096x65536x640 4096x65536x800 4096x65536x1024 4096x262144x256 4096x65536x16 4096x65536x32 > $out/shape_bench.log 2>&1; cat $out/shape_bench.log ;;
 esac; done
 find $out -name "*_agent_info.csv" -delete
