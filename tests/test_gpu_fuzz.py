@@ -1,5 +1,6 @@
-"""Random shapes through every kernel family against the CPU oracle: M, N in 1 .. 3000, K in 1 .. 600 with the edges of the
-dispatch tables drawn more often (K = 16 / 17, 256 / 257, 512 / 513 ...), the automatic kernel choice or a family forced where it
+"""Random shapes through every kernel family against the CPU oracle: M, N in 1 .. 3000, K in 1 .. 600 (half of the cases) or 1 .. 1100
+(the wave-pair kernel's every KTH and the operator path above 1024; round 5) with the edges of the
+dispatch tables drawn more often (K = 16 / 17, 256 / 257, 512 / 513, 576 / 577, 1024 / 1025 ...), the automatic kernel choice or a family forced where it
 applies, random split overrides, either quotient, graph replay or eager launches; a few iterations each against the oracle's
 update_div (cuda/nmf.cu:118-176), W and H within 5e-6 rel-Frobenius and the KL value (cuda/matrix.cu:592) within 5e-5 (+ 1e-6 of sum(X): cancellation).
 The suite runs 60 cases of seed 0 (+ 24 through update_div_restarts and the emulated-shards driver); `python tests/test_gpu_fuzz.py <cases> <seed>
@@ -12,7 +13,7 @@ import numpy as np
 import pytest
 
 EDGE_DIMS = (1, 16, 31, 32, 33, 64, 127, 128, 129, 1024)
-EDGE_K = (1, 3, 8, 15, 16, 17, 30, 32, 33, 48, 100, 255, 256, 257, 272, 300, 400, 496, 512, 513)
+EDGE_K = (1, 3, 8, 15, 16, 17, 30, 32, 33, 48, 100, 255, 256, 257, 272, 300, 400, 496, 512, 513, 528, 544, 560, 576, 577, 600, 608, 640, 700, 736, 900, 992, 1024, 1025)
 
 
 def run_fuzz(ng, oracle, n_cases, seed, verbose=False, large=False):
@@ -22,7 +23,8 @@ def run_fuzz(ng, oracle, n_cases, seed, verbose=False, large=False):
     for case in range(n_cases):
         M = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
         N = int(rng.integers(1, 3001)) if rng.random() < 0.8 else int(rng.choice(EDGE_DIMS))
-        K = int(rng.integers(1, 601)) if rng.random() < 0.7 else int(rng.choice(EDGE_K))
+        rk = rng.random()
+        K = int(rng.integers(1, 601)) if rk < 0.5 else (int(rng.integers(1, 1101)) if rk < 0.7 else int(rng.choice(EDGE_K)))
         if large:
             M, N, K = int(rng.integers(64, 4097)), int(rng.integers(3000, 70001)), int(rng.integers(1, 301))
             if rng.random() < 0.3:

@@ -399,14 +399,14 @@ def test_check_in_one_log_per_element_matches_an_fp64_evaluation(ng, oracle, M, 
     assert abs(kl - klo) <= 2e-6 * abs(klo), (kl, klo)
 
 
-# ------------------------------------------------------------------------------------------------ 512 < K <= 1024
-@pytest.mark.parametrize("M,N,K", [(256, 384, 640), (200, 130, 1000), (96, 520, 768), (320, 64, 900), (33, 70, 513), (700, 300, 1024)])
+# ------------------------------------------------------------------------------------------------ 512 < K <= 1024 (the wave-pair kernel from 577)
+@pytest.mark.parametrize("M,N,K", [(256, 384, 640), (200, 130, 1000), (96, 520, 768), (320, 64, 900), (33, 70, 513), (700, 300, 1024), (65, 129, 577)])
 def test_wave_pair_kernel_half_steps(ng, oracle, M, N, K):
     """nmf_pair16.hip: two waves share 16 owned columns and split K.  One update_h, one update_w (cuda/nmf.cu:118-176) on
     ragged sizes (K = 513 now runs the 64-column kernel on 528; the others the wave-pair kernel on 640, 1024, 768, 928, 1024), against the oracle and the operator path"""
     X, W, H = oracle.gen_problem(M, N, K, seed=7)
     s = ng.Solver(M, N, K, use_graph=False)
-    assert s.path == ng.PATH_FUSED and "pair" in s.describe()
+    assert s.path == ng.PATH_FUSED and ("pair" if K > 576 else "k16<KT=33>") in s.describe()
     s.upload(W, H, X)
     s.update_h()
     W1, H1 = s.download()
