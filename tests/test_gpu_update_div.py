@@ -633,7 +633,7 @@ def test_k_above_fused_limit_takes_unfused_path(ng, oracle):
 
 
 def test_random_shape_sweep(ng, oracle):
-    """seeded sweep over ragged shapes across every kernel instantiation (split kernel, K tiles 1/2/4/8, NB 5..8, wave pairs NBH 5..8, operator path),
+    """seeded sweep over ragged shapes across every kernel instantiation (split kernel, the 64-column kernel up to K = 576, wave pairs KTH 19..32, operator path),
     automatic split counts, 3 iterations each, against the oracle"""
     rng = np.random.default_rng(2024)
     ks = [1, 7, 32, 33, 64, 100, 128, 200, 256, 257, 320, 333, 400, 448, 512, 513, 640, 700, 896, 1000, 1024, 1025]
