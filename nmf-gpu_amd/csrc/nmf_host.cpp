@@ -58,7 +58,7 @@ extern "C" const char *nmf_status_string(int st) {
         default: return "unknown status";
     }
 }
-extern "C" const char *nmf_version(void) { return "nmf_mi355x 0.4 (gfx950)"; }
+extern "C" const char *nmf_version(void) { return "nmf_mi355x 0.5 (gfx950)"; }
 
 extern "C" int nmf_device_count(void) {
     int n = 0;

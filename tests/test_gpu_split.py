@@ -85,16 +85,18 @@ def test_k_above_512_at_the_reference_granularity_200_iterations_vs_oracle(ng, o
     cuda/matrix.cu:88-95: the reference pads to 32 and nothing coarser).  200 iterations through the default path (hipGraph replay) on
     a small shape for every new K class -- a caller's K on and off the kernel's grid, odd and even KTH (remainder blocks of 4, 8, 12
     steps; K mod 64 = 32: padding rows in slabs and LDS) -- and on a larger one for two of them (K = 576: the 64-column kernel's largest;
-    700: wave pairs), against the oracle.  Bound 2e-5 (north_star gate: 1e-4).  Measured (profiles/r05_parity_k_above_512.txt): 5.3e-6 .. 7.1e-6 on W
-    and 7.4e-6 .. 1.0e-5 on H at 256 x 512 for K = 520 .. 1000, 7.1e-6 .. 1.2e-5 at 1024 x 2048 for K = 544 .. 900 -- two fp32 summation
-    orders over 200 iterations, growing slowly with K like cfg3's 9.5e-6 / 1.08e-5 at K = 256 (tests/test_gpu_update_div.py)."""
+    700: wave pairs), against the oracle.  Bound 3e-5 (north_star gate: 1e-4).  Measured (profiles/r05_parity_k_above_512.txt): 5.3e-6 ..
+    7.1e-6 on W and 7.4e-6 .. 1.0e-5 on H at 256 x 512 for K = 520 .. 1000; 1.2e-5 / 2.0e-5 at 512 x 2048 x 700.  That distance is the
+    ORACLE's fp32 summation noise, not the kernels': against float64 numpy the GPU's factors are within 3e-6 .. 6e-6 where the oracle's
+    are within 1e-5 .. 2e-5 (512 x 2048 x 700: GPU 3.7e-6 / 5.7e-6, oracle 1.16e-5 / 1.97e-5; the same at K = 448, 512, 576 and at
+    1024 x 2048 x 700: tools/k_vs_fp64.py -> profiles/r05_k_above_512_vs_fp64.log)."""
     X, W, H = oracle.gen_problem(M, N, K, seed=K)
     Wm, Hm = ng.Matrix(W), ng.Matrix(H)
     r = ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=200, use_graph=1)
     assert r["iterations"] == 200
     Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
     eW, eH = _relF(oracle, Wm.mat, Wr), _relF(oracle, Hm.mat, Hr)
-    assert eW < 2e-5 and eH < 2e-5 and np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all(), (eW, eH)
+    assert eW < 3e-5 and eH < 3e-5 and np.isfinite(Wm.mat).all() and np.isfinite(Hm.mat).all(), (eW, eH)
 
 
 def test_default_choice_is_the_split_kernel_for_small_problems_only(ng):
