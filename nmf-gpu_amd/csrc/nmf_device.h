@@ -174,18 +174,12 @@ __device__ __forceinline__ void quotient8(const float (&x)[8], const f32x4 &s0, 
 
 // Variants (NMF_FUSED_VARIANT), for K <= 256: unset = production choice (16-column kernel at two workgroups per CU for
 // K = 64/128/256, v3 for K = 32); 3 = v3 (32-column kernel) everywhere; 1 = first chunk-serial kernel (64-bit addressing,
-// ablation probes).  NMF_FAST_DIVIDE=1 selects the refined-reciprocal quotient (<= 1 ulp) in variant 3.
+// ablation probes).
 inline int fused_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("NMF_FUSED_VARIANT"); v = (e && (e[0] == '1' || e[0] == '3')) ? (e[0] - '0') : 0; }   // 0 = automatic choice
     return v;
 }
-inline int fused_fast_divide() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("NMF_FAST_DIVIDE"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
 // grid of the grid-stride elementwise kernels
 inline unsigned ew_grid(size_t n) {
     size_t g = (n + 255) / 256;

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 ROUND=${ROUND:-r05}
 out=gpurun_out/${ROUND}_profile
 mkdir -p $out
-stages=${@:-bench kstats pmc small restarts shapes}
+stages=${@:-bench kstats pmc small restarts shapes}   # also: pmck
 for st in $stages; do case $st in
 bench)
   timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 > $out/bench_cfg3.json 2> $out/bench_cfg3.err; cut -c1-400 $out/bench_cfg3.json ;;
@@ -22,6 +22,17 @@ pmc)
   done
   python3 tools/pmc_summary.py --json $out/pmc_static.json --shape 4096x65536x256 --source "profiles/${ROUND}_pmc_summary.md: rocprofv3 --pmc passes of \`python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline\` (FETCH_SIZE x 2 + WRITE_SIZE; not this run)" \
       $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_insts > $out/pmc_summary.txt 2>&1; cat $out/pmc_summary.txt ;;
+pmck)
+  # the same four counter passes on other K at 4096 x 65536 (PMCK="576 640 1024": the largest 64-column kernel, the wave-pair kernel)
+  for K in ${PMCK:-576 640 1024}; do
+    for grp in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "insts SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU"; do
+      set -- $grp; name=$1; shift
+      timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pmck${K}_$name -- python3 tools/small_iter.py 4096 65536 $K 0 4 -1 > $out/pmck${K}_$name.log 2>&1
+    done
+    { echo "# ${ROUND} PMC summary — 4096 x 65536 x $K (four --pmc passes of tools/small_iter.py 4096 65536 $K 0 4 -1; tools/pmc_summary.py)"; echo
+      python3 tools/pmc_summary.py $out/pmck${K}_fetch $out/pmck${K}_write $out/pmck${K}_sq $out/pmck${K}_insts; } > $out/pmc_k$K.md 2>&1
+    grep "fused_step_kernel.*SIMD-cycles" $out/pmc_k$K.md | cut -c1-260
+  done ;;
 small)
   for pr in cfg2 gold gold100 gold200 paper; do
     timeout -k 10 120 python3 bench.py --preset $pr --steps 200 --warmup 41 --cpu-budget 4 > $out/bench_$pr.json 2> $out/bench_$pr.err; cut -c100-330 $out/bench_$pr.json
