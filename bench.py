@@ -114,8 +114,8 @@ def cpu_baseline(M, Nfull, K, budget_s=20.0, full=None):
     Ns = min(Nfull, 8192)
     if full is not None and full[0].shape[1] == Nfull and Nfull > Ns:
         Xs, Ws, Hs = full[0][:, :Ns], full[1], full[2][:, :Ns]          # the same generator, seed 0: the benchmark's own first columns
-        tf_s, it_s, t_s = timed(np.asfortranarray(Xs), Ws, np.asfortranarray(Hs), 0.35 * budget_s, 3, 200)
-        tf, iters, t = timed(full[0], full[1], full[2], 0.65 * budget_s, 3, 12)
+        tf_s, it_s, t_s = timed(np.asfortranarray(Xs), Ws, np.asfortranarray(Hs), 0.25 * budget_s, 3, 200)
+        tf, iters, t = timed(full[0], full[1], full[2], 0.5 * budget_s, 3, 12)
         return {"value": tf, "unit": "TFLOP/s", "cores": cores, "kind": "port",
                 "sample": f"{what}, M={M} K={K}, {Nfull} of {Nfull} columns (the benchmark's own X, W, H), {iters} iterations in {t:.1f} s after one warm-up iteration"
                           f" ({build} build); = {tf * 1e12 / (8.0 * M * Nfull * K):.4f} full-size iterations/s",
