@@ -161,16 +161,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             asm volatile("" : "+s"(base));
             xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
         };
-        // (vlf: the same image 64 KiB further on, for the pieces a ds_write's immediate offset does not reach: see the reads below)
-        constexpr int kFarSt = 16384;
-        auto stage_store_one = [&](float *__restrict__ vl, float *__restrict__ vlf, int w) {
+        auto stage_store_one = [&](float *__restrict__ vl, int w) {
             const int q = w / 4, cc = w % 4;
-            const int off = !WSTEP ? 32 * q * kLdv + cc : (32 * q + cc) * kLdv;                          // the part the thread does not decide
-            if (VBUF > kFarSt && off >= kFarSt) {
-                const int mine = !WSTEP ? (tid >> 3) * kLdv + 4 * (tid & 7) : 4 * (tid & 7) * kLdv + ((tid >> 3) & 31);
-                vlf[mine + (off - kFarSt)] = st[q][cc];
-            } else if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
-            else               { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
+            if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
+            else        { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
         };
         auto x_relayout = [&]() {
             if (!WSTEP) {
@@ -199,7 +193,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             for (int i = 0; i < 2; ++i) x_load_one(i);
         }
 #pragma unroll
-        for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, smem + kFarSt, w);
+        for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, w);
         if (!GEMM) x_relayout();
         __syncthreads();
         for (int ch = c_begin; ch < c_end; ++ch) {
@@ -211,20 +205,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            // A ds_read's immediate offset ends at 64 KiB; an image of K > 496 is longer (K = 576: 74 KiB), and every read beyond would get a
-            // v_add_u32 of its own -- VALU work the f32 MFMA cannot overlap (80 of them per chunk at K = 576).  Second bases 64 KiB further on.
-            constexpr int kFar = 16384;   // floats
-            constexpr bool FAR = VBUF > kFar;
-            // (made opaque: the compiler would fold `base + 64 KiB + off` back into one address and split it per access again)
-            auto far_base = [](const lds_float *b) { const lds_float *f = b + kFar; asm volatile("" : "+v"(f)); return f; };
-            const lds_float *b1f = FAR ? far_base(b1) : b1, *b1rf = FAR ? far_base(b1r) : b1r;
-            float *vnf = vn;
-            if (FAR) { vnf = vn + kFar; asm volatile("" : "+v"(vnf)); }
-            auto a1_ld = [&](int e) {
-                const int off = k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1);
-                const bool rem = k16_in_rem<NF>(e >> 1);
-                return (FAR && off >= kFar) ? lds_ld((rem ? b1rf : b1f) + (off - kFar)) : lds_ld((rem ? b1r : b1) + off);
-            };
+            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<NF>(e >> 1) ? b1r : b1) + k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
             // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
             float vs_in = 0.f;
             if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
@@ -267,7 +248,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (e >= ES && (e - ES) % SS == 0 && (e - ES) / SS < 4 * NST) {
-                        stage_store_one(vn, vnf, (e - ES) / SS);
+                        stage_store_one(vn, (e - ES) / SS);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
@@ -306,13 +287,8 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             const lds_float *b2 = (const lds_float *)vb + p2_off;
             constexpr int E2 = 8 * NT;   // order: (T, r) outer, tile t inner
             float a2[D];
-            const lds_float *b2f = FAR ? far_base(b2) : b2;
-            auto a2_ld = [&](int t, int g) {
-                const int off = 16 * t * kLdv + 16 * (g >> 2) + (g & 3);
-                return (FAR && off >= kFar) ? lds_ld(b2f + (off - kFar)) : lds_ld(b2 + off);
-            };
 #pragma unroll
-            for (int e = 0; e < D; ++e) a2[e] = a2_ld(e % NT, e / NT);
+            for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
             float z[8];
             asm volatile("s_nop 5" : "+v"(s0), "+v"(s1));   // D = 8 ds_reads + 6: the wait states of product 1's last MFMAs
             __builtin_amdgcn_sched_barrier(0);
@@ -331,10 +307,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     acc[t] = NMF_MFMA16(a2[e % D], z[g], acc[t]);
                     if (e + D < E2) {
                         const int en = e + D, gn = en / NT, tn = en % NT;
-                        a2[e % D] = a2_ld(tn, gn);
+                        a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
                     }
                     if (e >= E0 && (e - E0) % 2 == 0 && (e - E0) / 2 < 4 * NST) {
-                        stage_store_one(vn, vnf, (e - E0) / 2);
+                        stage_store_one(vn, (e - E0) / 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
