@@ -163,6 +163,7 @@ int  nmf_create_matrix(matrix *A, int rows, int cols, float value);   /* host al
 void nmf_destroy_matrix(matrix *A);                                   /* frees mat and mat_d */
 int  nmf_read_matrix(matrix *A, const char *file);                    /* cuda/nmf.cu:188-218 (no clamp: host copy stays raw) */
 int  nmf_write_matrix(matrix A, const char *file);                    /* cuda/nmf.cu:220-259 */
+int  nmf_matrix_alloc_device(matrix *A, int rows, int cols);   /* device buffer only, contents undefined (Matrix(rows, cols), cuda/matrix.cu:42-51) */
 int  nmf_matrix_to_device(matrix *A);      /* allocates mat_d if NULL, H2D (cuda/matrix.cu:53-67) */
 int  nmf_matrix_from_device(matrix *A);    /* D2H into mat (cuda/nmf.cu:228-232) */
 int  nmf_matrix_free_device(matrix *A);

@@ -72,6 +72,7 @@ _SIGS = [
     ("nmf_destroy_matrix", None, [C.POINTER(_matrix)]),
     ("nmf_read_matrix", C.c_int, [C.POINTER(_matrix), C.c_char_p]),
     ("nmf_write_matrix", C.c_int, [_matrix, C.c_char_p]),
+    ("nmf_matrix_alloc_device", C.c_int, [C.POINTER(_matrix), C.c_int, C.c_int]),
     ("nmf_matrix_to_device", C.c_int, [C.POINTER(_matrix)]),
     ("nmf_matrix_from_device", C.c_int, [C.POINTER(_matrix)]),
     ("nmf_matrix_free_device", C.c_int, [C.POINTER(_matrix)]),

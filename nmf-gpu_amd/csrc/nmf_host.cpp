@@ -1984,6 +1984,14 @@ extern "C" int nmf_create_matrix(matrix *A, int rows, int cols, float value) {
     A->dim[0] = rows; A->dim[1] = cols;
     return NMF_OK;
 }
+// Matrix(rows, cols), cuda/matrix.cu:42-51: a device buffer of that shape and nothing else (no host copy; contents undefined)
+extern "C" int nmf_matrix_alloc_device(matrix *A, int rows, int cols) {
+    if (!A || rows <= 0 || cols <= 0) return NMF_ERR_ARG;
+    A->mat = nullptr; A->mat_d = nullptr;
+    A->dim[0] = rows; A->dim[1] = cols;
+    HIPCHK(hipMalloc((void **)&A->mat_d, (size_t)rows * cols * sizeof(float)));
+    return NMF_OK;
+}
 extern "C" int nmf_matrix_free_device(matrix *A) {
     if (!A) return NMF_ERR_ARG;
     if (A->mat_d) { HIPCHK(hipFree(A->mat_d)); A->mat_d = nullptr; }

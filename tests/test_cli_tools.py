@@ -89,9 +89,46 @@ def _build_example(tmp_path, name):
     exe = tmp_path / "bin" / name
     exe.parent.mkdir(exist_ok=True)
     pkg = os.path.join(ROOT, "nmf-gpu_amd")
-    subprocess.run(["g++", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
                     "-L", pkg, "-lnmf_mi355x", f"-Wl,-rpath,{pkg}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], check=True)
     return exe
+
+
+def test_snapshot_main_on_the_cxx_surface_compiles_and_links(tmp_path):
+    """include/nmf_mi355x.hpp -- the snapshot's own C++ surface (class Matrix, matrix_multiply ..., read_matrix, run_async:
+    cuda/matrix.cuh:18-52, cuda/nmf.cu:13-28) as a header-only layer over the C ABI -- and the snapshot's main() written on it
+    (examples/snapshot_main.cpp) build with the host compiler alone; without ../X.bin the program ends like the reference's
+    read_matrix would if it checked fopen: a message and a non-zero exit (error-check.hpp:12-17)."""
+    exe = _build_example(tmp_path, "snapshot_main")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, cwd=exe.parent, timeout=60)
+    assert r.returncode != 0 and "read_matrix" in r.stderr and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_snapshot_main_runs_and_its_operator_iteration_agrees_with_the_fused_loop(oracle, tmp_path):
+    """'may additionally offer a C++ Matrix-like RAII wrapper mirroring matrix.cuh:18-39'.  (i) The snapshot's main on
+    that surface -- read_matrix x 3, run_async, write_matrix x 2 (cuda/nmf.cu:30-51) -- against the oracle after its 200
+    iterations; (ii) the reference's own iteration, update_h / update_w as sixteen calls of the mirrored operators
+    (cuda/nmf.cu:118-176: matrix_multiply, set_epsilon, element_divide, sum_cols, matrix_multiply_AtB, col_divide,
+    element_multiply; ... sum_rows, matrix_multiply_ABt, row_divide ...), 20 iterations on the same files: against the oracle,
+    and against run_async's fused loop (the two differ in summation order only)."""
+    exe = _build_example(tmp_path, "snapshot_main")
+    assert _run("generate", "--M", "700", "--N", "450", "--K", "96", cwd=tmp_path).returncode == 0
+    X, W, H = (oracle.read_bin(str(tmp_path / f)) for f in ("X.bin", "W.bin", "H.bin"))
+    r = subprocess.run([str(exe)], capture_output=True, text=True, cwd=exe.parent, timeout=300)
+    assert r.returncode == 0, r.stderr
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 200, 25)
+    assert oracle.relF(oracle.read_bin(str(tmp_path / "Wout.bin")), Wr) < 1e-5
+    assert oracle.relF(oracle.read_bin(str(tmp_path / "Hout.bin")), Hr) < 1e-5
+    r = subprocess.run([str(exe), "operators", "20"], capture_output=True, text=True, cwd=exe.parent, timeout=300)
+    assert r.returncode == 0, r.stderr
+    Wo, Ho = oracle.read_bin(str(tmp_path / "Wout.bin")), oracle.read_bin(str(tmp_path / "Hout.bin"))
+    Wr, Hr, _, _ = oracle.update_div(W, H, X, 0.0, 20, 25)
+    assert oracle.relF(Wo, Wr) < 5e-6 and oracle.relF(Ho, Hr) < 5e-6
+    import nmf_gpu_amd as ng
+    Wm, Hm = ng.Matrix(W), ng.Matrix(H)
+    ng.update_div_ex(Wm, Hm, ng.Matrix(X), max_iter=20)
+    assert oracle.relF(Wo, Wm.mat) < 5e-6 and oracle.relF(Ho, Hm.mat) < 5e-6
 
 
 def test_sharded_main_compiles_and_links(tmp_path):
