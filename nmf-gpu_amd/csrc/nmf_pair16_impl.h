@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_pair(FusedArgs a, do
 #pragma unroll
                 for (int w = N1 / 2; w < 4 * NST; ++w) stage_store_one(vn, w);   // K % 64 == 32: the zero padding of the last 64-column piece
             }
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+            // (no explicit wait states here: every MFMA of this kernel is a builtin, so the compiler's hazard recognizer pads the read of s0 / s1
+            //  itself.  Until round 5 an `s_nop 15; s_nop 3` statement stood here, a leftover of the inline-asm chain this kernel started with;
+            //  its "+v" operands also pinned both accumulators and the schedule around them: 1-2 % of the half-step, profiles/r05_pair_ablation.log)
             // ---- the two halves of S meet: both waves of the pair add them in the same order
             xch[wave * 64 + lane] = s0 + s1;
             __syncthreads();
