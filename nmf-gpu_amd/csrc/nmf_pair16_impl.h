@@ -39,22 +39,29 @@ __device__ __forceinline__ void quotient4(const float (&x)[4], const f32x4 &s, f
     for (int r = 1; r < 4; ++r) { const unsigned b = __float_as_uint(s[r]); m = b > m ? b : m; }
     const bool fast = in_range && __builtin_amdgcn_ballot_w64(m > __float_as_uint(kDivSafeMax)) == 0;
     if (fast) {
+        // quotient<1>, stage by stage on two packed pairs (v_pk_fma_f32 / v_pk_mul_f32: half the instructions of the scalar form), as quotient8
         const float eps = kEps;
-        float y[4], rc[4], e[4], q[4];
+        float y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm("v_max_f32 %0, %1, %2" : "=v"(y[r]) : "v"(s[r]), "v"(eps));
+        f32x2 yy[2], xx[2], rc[2], q[2], e[2];
+        const f32x2 one = {1.0f, 1.0f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rc[r] = __builtin_amdgcn_rcpf(y[r]);
+        for (int i = 0; i < 2; ++i) { yy[i] = f32x2{y[2 * i], y[2 * i + 1]}; xx[i] = f32x2{x[2 * i], x[2 * i + 1]}; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_fmaf(-y[r], rc[r], 1.0f);
+        for (int i = 0; i < 2; ++i) rc[i] = f32x2{__builtin_amdgcn_rcpf(yy[i].x), __builtin_amdgcn_rcpf(yy[i].y)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rc[r] = __builtin_fmaf(e[r], rc[r], rc[r]);
+        for (int i = 0; i < 2; ++i) e[i] = __builtin_elementwise_fma(-yy[i], rc[i], one);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[r] = x[r] * rc[r];
+        for (int i = 0; i < 2; ++i) rc[i] = __builtin_elementwise_fma(e[i], rc[i], rc[i]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_fmaf(-y[r], q[r], x[r]);
+        for (int i = 0; i < 2; ++i) q[i] = xx[i] * rc[i];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[r] = __builtin_fmaf(e[r], rc[r], q[r]);
+        for (int i = 0; i < 2; ++i) e[i] = __builtin_elementwise_fma(-yy[i], q[i], xx[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) q[i] = __builtin_elementwise_fma(e[i], rc[i], q[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { z[2 * i] = q[i].x; z[2 * i + 1] = q[i].y; }
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[r] = x[r] / clamp_eps(s[r]);
