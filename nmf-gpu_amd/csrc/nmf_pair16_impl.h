@@ -6,7 +6,7 @@
 // (256 more) no longer fit one wave.  Here TWO WAVES SHARE 16 OWNED COLUMNS AND SPLIT K: wave h of a pair holds the B operands
 // and the accumulator rows of k in [h K/2, (h + 1) K/2).  Per 16-row chunk of the streamed factor
 //   1. each wave forms its half of S = V_chunk * U over its k range (two interleaved MFMA chains),
-//   2. the halves meet in LDS (1 KiB per wave), both waves add them in the same order and take the quotient Z = X ./ max(S, EPS),
+//   2. the halves meet in LDS (1 KiB per wave), both waves add the two halves (a + b = b + a bit for bit) and take the quotient Z = X ./ max(S, EPS),
 //   3. each wave accumulates Acc[k range] += V_chunk[:, k range]' * Z -- no MFMA is issued twice, no accumulator is shared.
 // Same v_mfma_f32_16x16x4_f32 lane maps as nmf_fused16_impl.h (lane l: j = l & 15, kq = l >> 4; A = A[row j][k kq],
 // B = B[k kq][col j], result register r = D[4 kq + r][j]); chunks are 16 rows so that the K x 16 LDS image (row stride 17)
@@ -231,9 +231,11 @@ __global__ __launch_bounds__(256, 1) void fused_step_kernel_pair(FusedArgs a, do
             //  itself.  Until round 5 an `s_nop 15; s_nop 3` statement stood here, a leftover of the inline-asm chain this kernel started with;
             //  its "+v" operands also pinned both accumulators and the schedule around them: 1-2 % of the half-step, profiles/r05_pair_ablation.log)
             // ---- the two halves of S meet: both waves of the pair add them in the same order
-            xch[wave * 64 + lane] = s0 + s1;
+            // (each wave reads its partner's half only: a + b and b + a are the same bits, so both waves of the pair still hold the same S)
+            const f32x4 mine = s0 + s1;
+            xch[wave * 64 + lane] = mine;
             __syncthreads();
-            const f32x4 s = xch[(2 * pair) * 64 + lane] + xch[(2 * pair + 1) * 64 + lane];
+            const f32x4 s = mine + xch[(wave ^ 1) * 64 + lane];
             if (CHECK) {
                 if (h == 0) {
                     float fkl = 0.f, fd = 0.f;
