@@ -102,6 +102,12 @@ def test_snapshot_main_on_the_cxx_surface_compiles_and_links(tmp_path):
     exe = _build_example(tmp_path, "snapshot_main")
     r = subprocess.run([str(exe)], capture_output=True, text=True, cwd=exe.parent, timeout=60)
     assert r.returncode != 0 and "read_matrix" in r.stderr and "cannot open" in r.stderr
+    # the header is plain C++17: clean under -Wall -Wextra -pedantic with both host compilers
+    for cxx in ("g++", "/opt/rocm/lib/llvm/bin/clang++"):
+        if cxx.startswith("/") and not os.path.exists(cxx):
+            continue
+        subprocess.run([cxx, "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "snapshot_main.cpp")], check=True)
 
 
 @pytest.mark.gpu
