@@ -161,10 +161,19 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             asm volatile("" : "+s"(base));
             xg[i] = *(const __attribute__((address_space(1))) f32x4 *)(base + xo);
         };
-        auto stage_store_one = [&](float *__restrict__ vl, int w) {
+        // An LDS access's immediate offset ends at 64 KiB; an image of K > 496 is longer (K = 576: 74 KiB) and every access beyond would get a
+        // v_add_u32 of its own (81 per chunk at K = 576: VALU work the f32 MFMA cannot overlap).  FAR kernels keep second bases 64 KiB further on,
+        // made opaque ONCE, outside the chunk loop (inside it an asm statement pins the schedule: tried, slower -- HISTORY.md); the loop adds the
+        // image's parity offset to them.
+        constexpr int kFar = 16384;   // floats
+        constexpr bool FAR = VBUF > kFar;
+        typedef __attribute__((address_space(3))) float lds_wfloat;
+        auto stage_store_one = [&](float *__restrict__ vl, lds_wfloat *vlf, int w) {
             const int q = w / 4, cc = w % 4;
-            if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
-            else        { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
+            const int off = !WSTEP ? 32 * q * kLdv + cc : (32 * q + cc) * kLdv;      // the part of the index the thread does not decide
+            if (FAR && off >= kFar) vlf[off - kFar] = st[q][cc];                    // vlf already holds the thread's part
+            else if (!WSTEP) { const int k = (tid >> 3) + 32 * q, i4 = tid & 7; vl[k * kLdv + 4 * i4 + cc] = st[q][cc]; }
+            else             { const int k4 = q * 8 + (tid & 7), i = (tid >> 3) & 31; vl[(4 * k4 + cc) * kLdv + i] = st[q][cc]; }
         };
         auto x_relayout = [&]() {
             if (!WSTEP) {
@@ -193,19 +202,28 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             for (int i = 0; i < 2; ++i) x_load_one(i);
         }
 #pragma unroll
-        for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, w);
+        for (int w = 0; w < 4 * NST; ++w) stage_store_one(smem, (lds_wfloat *)smem + (!WSTEP ? (tid >> 3) * kLdv + 4 * (tid & 7) : 4 * (tid & 7) * kLdv + ((tid >> 3) & 31)) + kFar, w);
         if (!GEMM) x_relayout();
         __syncthreads();
+        const lds_float *far1 = (const lds_float *)smem + p1_off + kFar, *far1r = (const lds_float *)smem + p1r_off + kFar, *far2 = (const lds_float *)smem + p2_off + kFar;
+        lds_wfloat *farst = (lds_wfloat *)smem + (!WSTEP ? (tid >> 3) * kLdv + 4 * (tid & 7) : 4 * (tid & 7) * kLdv + ((tid >> 3) & 31)) + kFar;
+        if (FAR) asm volatile("" : "+v"(far1), "+v"(far1r), "+v"(far2), "+v"(farst));
         for (int ch = c_begin; ch < c_end; ++ch) {
             const int par = (ch - c_begin) & 1;
             const float *__restrict__ vb = smem + par * VBUF;
             float *__restrict__ vn = smem + (par ^ 1) * VBUF;
+            const lds_float *b1f = far1 + par * VBUF, *b1rf = far1r + par * VBUF, *b2f = far2 + par * VBUF;
+            lds_wfloat *vnf = farst + (par ^ 1) * VBUF;
             const int chn = (ch + 1 < c_end) ? ch + 1 : ch;
             set_chunk(chn);
             // ---- product 1: two interleaved chains, step index e = 2 s + T
             const lds_float *b1 = (const lds_float *)vb + p1_off;
             const lds_float *b1r = (const lds_float *)vb + p1r_off;
-            auto a1_ld = [&](int e) { return lds_ld((k16_in_rem<NF>(e >> 1) ? b1r : b1) + k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1)); };
+            auto a1_ld = [&](int e) {
+                const int off = k16_kconst<NF, IL>(e >> 1) * kLdv + 16 * (e & 1);
+                const bool rem = k16_in_rem<NF>(e >> 1);
+                return (FAR && off >= kFar) ? lds_ld((rem ? b1rf : b1f) + (off - kFar)) : lds_ld((rem ? b1r : b1) + off);
+            };
             // W-step side product: this wave's row of the streamed H chunk, summed per lane (p = lane & 31) over the chunks
             float vs_in = 0.f;
             if (WSTEP && PARTIAL) { if (vsum_on) vs_in = lds_ld((const lds_float *)vb + vrow * kLdv + (lane & 31)); }
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (e >= ES && (e - ES) % SS == 0 && (e - ES) / SS < 4 * NST) {
-                        stage_store_one(vn, (e - ES) / SS);
+                        stage_store_one(vn, vnf, (e - ES) / SS);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (e >= G && e % G == 0 && e / G - 1 < NLOAD) {
@@ -285,10 +303,14 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
             }
             // ---- first operands of product 2, then the quotient in one VALU block
             const lds_float *b2 = (const lds_float *)vb + p2_off;
+            auto a2_ld = [&](int t, int g) {
+                const int off = 16 * t * kLdv + 16 * (g >> 2) + (g & 3);
+                return (FAR && off >= kFar) ? lds_ld(b2f + (off - kFar)) : lds_ld(b2 + off);
+            };
             constexpr int E2 = 8 * NT;   // order: (T, r) outer, tile t inner
             float a2[D];
 #pragma unroll
-            for (int e = 0; e < D; ++e) a2[e] = lds_ld(b2 + 16 * (e % NT) * kLdv + 16 * ((e / NT) >> 2) + ((e / NT) & 3));
+            for (int e = 0; e < D; ++e) a2[e] = a2_ld(e % NT, e / NT);
             float z[8];
             asm volatile("s_nop 5" : "+v"(s0), "+v"(s1));   // D = 8 ds_reads + 6: the wait states of product 1's last MFMAs
             __builtin_amdgcn_sched_barrier(0);
@@ -307,10 +329,10 @@ __global__ __launch_bounds__(256, OCC) void fused_step_kernel_k16(FusedArgs a, d
                     acc[t] = NMF_MFMA16(a2[e % D], z[g], acc[t]);
                     if (e + D < E2) {
                         const int en = e + D, gn = en / NT, tn = en % NT;
-                        a2[e % D] = lds_ld(b2 + 16 * tn * kLdv + 16 * (gn >> 2) + (gn & 3));
+                        a2[e % D] = a2_ld(tn, gn);
                     }
                     if (e >= E0 && (e - E0) % 2 == 0 && (e - E0) / 2 < 4 * NST) {
-                        stage_store_one(vn, (e - E0) / 2);
+                        stage_store_one(vn, vnf, (e - E0) / 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
