@@ -28,3 +28,13 @@ def test_no_inline_asm_mfma_of_the_shipped_kernels_sits_in_a_hazard_window():
         assert family in kernels, (family, sorted(kernels)[:5])
     with_asm = [r for r in rows if r[9] > 0]
     assert with_asm and all(r[6] == 0 and r[7] == 0 for r in with_asm)      # no scratch, no spills next to asm MFMAs
+    # The f32 MFMA shares the VALU datapath: address arithmetic and register copies inside the chunk loop are MFMA issue time.  The production
+    # half-step kernels of the 64-column and the wave-pair family keep them to a handful per chunk (round 5: the K = 576 kernel had 81 v_add_u32
+    # per chunk, one per LDS access beyond the 64 KiB an immediate offset reaches, and ran at 82 % instead of 90 % of peak).
+    worst = {}
+    for r in rows:
+        fam = r[1].split("<")[0]
+        if fam in ("nmf::fused_step_kernel_k16", "nmf::fused_step_kernel_pair") and r[10] >= 16:
+            worst[fam] = max(worst.get(fam, 0), r[11])
+            assert r[11] <= 48 and r[11] <= max(8, 0.35 * r[10]), (r[1], r[10], r[11])
+    assert set(worst) == {"nmf::fused_step_kernel_k16", "nmf::fused_step_kernel_pair"}, worst

@@ -238,6 +238,29 @@ def audit_kernel(name, code):
     return n_asm, hazards
 
 
+ADDR_COPY_OPS = ("v_add_u32", "v_add3_u32", "v_lshl_add_u32", "v_mad_u32_u24", "v_accvgpr_read", "v_accvgpr_write", "v_mov_b32")
+
+
+def chunk_loop_overhead(code):
+    """(MFMAs, address-arithmetic / register-copy VALU instructions) inside the kernel's longest backward-branch region -- the chunk loop of
+    the half-step kernels.  The f32 MFMA shares the VALU datapath, so every such instruction is MFMA issue time; round 5 found 81 of them per
+    chunk in the K = 576 kernel (one v_add_u32 per LDS access beyond the 64 KiB an immediate offset reaches: 82 % instead of 90 % of peak)."""
+    label_at = {}
+    for i, ins in enumerate(code):
+        for lab in ins.labels:
+            label_at[lab] = i
+    best = None
+    for i, ins in enumerate(code):
+        if ins.op.startswith("s_cbranch") and ins.ops and ins.ops[0] in label_at and label_at[ins.ops[0]] < i:
+            span = (label_at[ins.ops[0]], i)
+            if best is None or span[1] - span[0] > best[1] - best[0]:
+                best = span
+    if best is None:
+        return 0, 0
+    loop = code[best[0]:best[1]]
+    return sum(1 for c in loop if c.is_mfma()), sum(1 for c in loop if c.op.startswith(ADDR_COPY_OPS))
+
+
 def resources(path):
     """per-kernel register / LDS / scratch figures from the amdhsa metadata at the end of the .s"""
     out, cur = {}, None
@@ -286,17 +309,20 @@ def run(outdir=None, report=None):
             if n_asm and (spill or scratch):
                 all_hazards.append(f"{pretty[name]}: {spill} spilled registers, {scratch} bytes of scratch in a kernel with inline-asm MFMAs")
             n_mfma = sum(1 for c in code if c.is_mfma())
+            loop_mfma, loop_over = chunk_loop_overhead(code)
             rows.append((unit, pretty[name].split("(")[0].replace("void ", ""), r.get(".vgpr_count", "?"), r.get(".agpr_count", "?"), r.get(".sgpr_count", "?"),
-                         r.get(".group_segment_fixed_size", "?"), scratch, spill, n_mfma, n_asm))
+                         r.get(".group_segment_fixed_size", "?"), scratch, spill, n_mfma, n_asm, loop_mfma, loop_over))
     if report:
         with open(report, "w") as f:
             f.write("# kernel resources and inline-asm MFMA audit (tools/asm_audit.py; hipcc -S with the Makefile's flags, gfx950)\n\n")
             f.write("VGPR / AGPR / SGPR counts, static LDS bytes (the fused kernels add dynamic LDS at launch), scratch bytes, spilled registers, MFMA "
-                    "instructions in the kernel's code, and how many of those sit inside `asm volatile` statements.  Every asm MFMA was checked for a VALU "
+                    "instructions in the kernel's code, how many of those sit inside `asm volatile` statements, and -- for the longest loop of the kernel, the chunk loop of "
+                    "the half-step kernels -- its MFMAs next to its address-arithmetic / register-copy VALU instructions (v_add_u32, v_add3, v_lshl_add, v_mad_u32_u24, "
+                    "v_accvgpr_*, v_mov: MFMA issue time on this datapath).  Every asm MFMA was checked for a VALU "
                     f"write of one of its operands within {OPERAND_WAIT} wait states before it and for any non-accumulating touch of its result within "
                     f"{RESULT_WAIT['16x16x4']} (16x16x4) / {RESULT_WAIT['32x32x2']} (32x32x2) wait states after it, along every control-flow path.\n\n")
             f.write(f"**{n_asm_total} inline-asm MFMAs audited, {len(all_hazards)} hazards.**\n\n")
-            f.write("| unit | kernel | VGPR | AGPR | SGPR | static LDS | scratch | spills | MFMAs | in asm |\n|---|---|---|---|---|---|---|---|---|---|\n")
+            f.write("| unit | kernel | VGPR | AGPR | SGPR | static LDS | scratch | spills | MFMAs | in asm | loop MFMAs | loop addr/copy VALU |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
             for row in rows:
                 f.write("| " + " | ".join(str(c) for c in row) + " |\n")
             if all_hazards:
