@@ -251,7 +251,7 @@ def chunk_loop_overhead(code):
             label_at[lab] = i
     best = None
     for i, ins in enumerate(code):
-        if ins.op.startswith("s_cbranch") and ins.ops and ins.ops[0] in label_at and label_at[ins.ops[0]] < i:
+        if ins.op.startswith(("s_cbranch", "s_branch")) and ins.ops and ins.ops[0] in label_at and label_at[ins.ops[0]] < i:
             span = (label_at[ins.ops[0]], i)
             if best is None or span[1] - span[0] > best[1] - best[0]:
                 best = span
