@@ -36,5 +36,5 @@ def test_no_inline_asm_mfma_of_the_shipped_kernels_sits_in_a_hazard_window():
         fam = r[1].split("<")[0]
         if fam in ("nmf::fused_step_kernel_k16", "nmf::fused_step_kernel_pair") and r[10] >= 16:
             worst[fam] = max(worst.get(fam, 0), r[11])
-            assert r[11] <= 64 and r[11] <= max(8, 0.35 * r[10]), (r[1], r[10], r[11])
+            assert r[11] <= (0.15 * r[10] if r[10] >= 256 else max(8, 0.35 * r[10])), (r[1], r[10], r[11])
     assert set(worst) == {"nmf::fused_step_kernel_k16", "nmf::fused_step_kernel_pair"}, worst
